@@ -1,0 +1,154 @@
+"""gnark-symmetric-crypto_amd — MI355X-native Groth16 prover behind the reference's libprove C-ABI.
+
+This package is only the Python-side loader of ``libprove.so`` (built from ``csrc/`` by ``csrc/Makefile``)
+plus thin helpers that call it exactly the way a foreign-function host (node.js / Go cgo) would:
+``GoSlice`` arguments by value, ``struct Prove_return`` results released with ``Free``
+(reference: libraries/prover/libprove.go:17-47).  There is no Python or CPU implementation of the prover
+here: if the shared library or a GPU is missing, calls fail loudly.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprove.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
+ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
+
+EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw",
+           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms"]
+
+
+class GoSlice(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_longlong), ("cap", C.c_longlong)]
+
+
+class ProveReturn(C.Structure):
+    _fields_ = [("r0", C.c_void_p), ("r1", C.c_longlong)]
+
+
+def build(jobs=8):
+    """Compile csrc/ into libprove.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", CSRC, "-j%d" % jobs], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libprove.so is not built: run gnark-symmetric-crypto_amd.build() (make -C %s)" % CSRC)
+        L = C.CDLL(LIB_PATH)
+        L.InitAlgorithm.restype = C.c_ubyte
+        L.InitAlgorithm.argtypes = [C.c_ubyte, GoSlice, GoSlice]
+        L.Free.argtypes = [C.c_void_p]
+        L.Prove.restype = ProveReturn
+        L.Prove.argtypes = [GoSlice]
+        L.ProveBatch.restype = ProveReturn
+        L.ProveBatch.argtypes = [GoSlice]
+        L.gsc_prove_raw.restype = C.c_longlong
+        L.gsc_prove_raw.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gsc_set_deterministic_randomness.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+        L.gsc_debug_prove.restype = C.c_longlong
+        L.gsc_debug_prove.argtypes = [GoSlice]
+        L.gsc_debug_vector.restype = C.c_longlong
+        L.gsc_debug_vector.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        L.gsc_describe.restype = C.c_size_t
+        L.gsc_describe.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t]
+        L.gsc_last_stage_ms.argtypes = [C.c_ubyte, C.POINTER(C.c_float)]
+        L.enforce_binding()
+        _lib = L
+    return _lib
+
+
+def _slice(b: bytes):
+    buf = C.create_string_buffer(b, len(b))
+    return GoSlice(C.cast(buf, C.c_void_p), len(b), len(b)), buf
+
+
+def init_algorithm(algorithm_id: int, proving_key: bytes, r1cs: bytes) -> bool:
+    """InitAlgorithm(algorithmID, provingKey, r1cs) — libprove.go:20-23."""
+    s1, k1 = _slice(proving_key)
+    s2, k2 = _slice(r1cs)
+    return bool(lib().InitAlgorithm(algorithm_id, s1, s2))
+
+
+def _take(ret: ProveReturn) -> bytes:
+    if not ret.r0:
+        return b""
+    out = C.string_at(ret.r0, ret.r1)
+    lib().Free(ret.r0)
+    return out
+
+
+def prove(params) -> bytes:
+    """Prove(params) — libprove.go:30-47.  params: bytes/str JSON or a dict.  Returns the raw JSON bytes."""
+    if isinstance(params, dict):
+        params = json.dumps(params)
+    if isinstance(params, str):
+        params = params.encode()
+    s, keep = _slice(params)
+    return _take(lib().Prove(s))
+
+
+def prove_batch(params_list) -> list:
+    """ProveBatch (addition): list of dicts -> list of decoded JSON results."""
+    s, keep = _slice(json.dumps(params_list).encode())
+    return json.loads(_take(lib().ProveBatch(s)))
+
+
+def prove_raw(cipher: int, records: bytes, n: int):
+    """Binary batch path: n records of 112 B {key[32], nonce[12], counter u32 LE, input[64]}.
+    Returns (n_ok, proofs[n][196], lens[n], ciphertexts[n][64])."""
+    proofs = C.create_string_buffer(196 * n)
+    lens = (C.c_uint32 * n)()
+    cts = C.create_string_buffer(64 * n)
+    ok = lib().gsc_prove_raw(cipher, records, n, proofs, lens, cts)
+    return ok, proofs.raw, list(lens), cts.raw
+
+
+def set_deterministic_randomness(r=None, s=None, mask=0):
+    """TEST HOOK: fix (r, s, mask) as integers; None restores the CSPRNG."""
+    if r is None:
+        lib().gsc_set_deterministic_randomness(None, None, None)
+    else:
+        lib().gsc_set_deterministic_randomness(int(r).to_bytes(32, "big"), int(s).to_bytes(32, "big"), int(mask).to_bytes(32, "big"))
+
+
+def debug_prove(params: dict):
+    """TEST HOOK: run one proof and return the device pipeline's intermediate vectors as lists of ints.
+    W/A/B/C come back in Montgomery form and are converted here with Python integers."""
+    r_mod = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+    rinv = pow(1 << 256, -1, r_mod)
+    s, keep = _slice(json.dumps(params).encode())
+    if lib().gsc_debug_prove(s) != 0:
+        raise RuntimeError("debug prove failed")
+    out = {}
+    for which, name, mont in ((0, "W", True), (1, "A", True), (2, "B", True), (3, "C", True), (4, "h", False)):
+        n = lib().gsc_debug_vector(which, None, 0)
+        buf = C.create_string_buffer(32 * n)
+        lib().gsc_debug_vector(which, buf, 32 * n)
+        vals = [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+        if mont:
+            vals = [v * rinv % r_mod for v in vals]
+        out[name] = vals
+    return out
+
+
+def describe(algorithm_id: int) -> str:
+    buf = C.create_string_buffer(1024)
+    lib().gsc_describe(algorithm_id, buf, 1024)
+    return buf.value.decode()
+
+
+def last_stage_ms(algorithm_id: int):
+    arr = (C.c_float * 4)()
+    if lib().gsc_last_stage_ms(algorithm_id, arr) != 0:
+        return None
+    return dict(zip(("witness", "quotient", "msm", "assembly"), list(arr)))

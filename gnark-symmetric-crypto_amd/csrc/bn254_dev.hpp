@@ -1,0 +1,314 @@
+// BN254 arithmetic for gfx950 (device only).
+//
+// Replaces, on the GPU, what the reference's hot path gets from gnark-crypto v0.14.0
+// (reference go.mod:9): ecc/bn254/fp, fr Montgomery arithmetic and the G1/G2 group law used by
+// groth16.Prove (libraries/prover/impl/provers.go:148,216).  Design notes:
+//   * 8 x 32-bit limbs, little-endian, Montgomery form with R = 2^256 (same residues as gnark-crypto's
+//     4 x 64-bit limbs, so values can be compared limb-for-limb with the oracle).
+//   * v_mad_u64_u32 is the workhorse: measured ~4.8 cycles / wave-instruction / SIMD, i.e. the same
+//     price as a carry-propagating 32-bit add (tools/ubench_intmul.hip, profiles/r01_ubench_intmul.txt).
+//   * No MFMA: 254-bit modular products are not a dense contraction.
+//   * Points: affine (x,y) for fixed bases / table entries, XYZZ (X, Y, ZZ, ZZZ) for accumulators:
+//     a mixed add is 8M + 2S with no inversion.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DEVFN __device__ __forceinline__
+#define DEVNOINL __device__ __noinline__
+// Cold translation units (init-time kernels) define BN254_OUTLINE_MUL to keep compile time and code size down.
+#ifdef BN254_OUTLINE_MUL
+#define DEVMUL __device__ __noinline__
+#else
+#define DEVMUL __device__ __forceinline__
+#endif
+
+namespace bn254 {
+
+struct FpParams {
+    DEVFN static constexpr uint32_t mod(int i) {
+        constexpr uint32_t m[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return m[i];
+    }
+    DEVFN static constexpr uint32_t one(int i) {   // R mod p
+        constexpr uint32_t m[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return m[i];
+    }
+    DEVFN static constexpr uint32_t r2(int i) {    // R^2 mod p
+        constexpr uint32_t m[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+        return m[i];
+    }
+    static constexpr uint32_t ninv = 0xe4866389u;  // -p^-1 mod 2^32
+};
+struct FrParams {
+    DEVFN static constexpr uint32_t mod(int i) {
+        constexpr uint32_t m[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return m[i];
+    }
+    DEVFN static constexpr uint32_t one(int i) {   // R mod r
+        constexpr uint32_t m[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return m[i];
+    }
+    DEVFN static constexpr uint32_t r2(int i) {    // R^2 mod r
+        constexpr uint32_t m[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return m[i];
+    }
+    static constexpr uint32_t ninv = 0xefffffffu;
+};
+
+struct alignas(16) fe {
+    uint32_t l[8];
+};
+
+template <class P>
+struct Field {
+    using E = fe;
+
+    DEVFN static E zero() { E r; for (int i = 0; i < 8; i++) r.l[i] = 0; return r; }
+    DEVFN static E one() { E r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = P::one(i);
+        return r; }
+    DEVFN static E r2() { E r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = P::r2(i);
+        return r; }
+    DEVFN static bool is_zero(const E& a) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= a.l[i];
+        return o == 0;
+    }
+    DEVFN static bool eq(const E& a, const E& b) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
+        return o == 0;
+    }
+    // r = a - p if a >= p else a     (a < 2p)
+    DEVFN static E reduce_once(const E& a) {
+        E t; uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t d = (uint64_t)a.l[i] - P::mod(i) - br;
+            t.l[i] = (uint32_t)d; br = (d >> 32) & 1;
+        }
+        E r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = br ? a.l[i] : t.l[i];
+        return r;
+    }
+    DEVFN static E add(const E& a, const E& b) {
+        E t; uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)a.l[i] + b.l[i]; t.l[i] = (uint32_t)c; c >>= 32; }
+        return reduce_once(t);   // p < 2^254: no carry out of limb 7
+    }
+    DEVFN static E dbl(const E& a) { return add(a, a); }
+    DEVFN static E sub(const E& a, const E& b) {
+        E t; uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t d = (uint64_t)a.l[i] - b.l[i] - br;
+            t.l[i] = (uint32_t)d; br = (d >> 32) & 1;
+        }
+        uint32_t mask = (uint32_t)0 - (uint32_t)br;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)t.l[i] + (P::mod(i) & mask); t.l[i] = (uint32_t)c; c >>= 32; }
+        return t;
+    }
+    DEVFN static E neg(const E& a) {
+        E t; uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t d = (uint64_t)P::mod(i) - a.l[i] - br;
+            t.l[i] = (uint32_t)d; br = (d >> 32) & 1;
+        }
+        bool z = is_zero(a);
+#pragma unroll
+        for (int i = 0; i < 8; i++) t.l[i] = z ? 0u : t.l[i];
+        return t;
+    }
+    // Montgomery product a*b*R^-1 mod p, operand-scanning CIOS on 32-bit limbs.
+    DEVMUL static E mul(const E& a, const E& b) {
+        uint32_t t[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                c += (uint64_t)a.l[j] * b.l[i] + t[j];
+                t[j] = (uint32_t)c; c >>= 32;
+            }
+            c += t[8]; t[8] = (uint32_t)c; t[9] = (uint32_t)(c >> 32);
+            uint32_t m = t[0] * P::ninv;
+            c = (uint64_t)m * P::mod(0) + t[0]; c >>= 32;
+#pragma unroll
+            for (int j = 1; j < 8; j++) {
+                c += (uint64_t)m * P::mod(j) + t[j];
+                t[j - 1] = (uint32_t)c; c >>= 32;
+            }
+            c += t[8]; t[7] = (uint32_t)c; t[8] = t[9] + (uint32_t)(c >> 32);
+        }
+        E r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = t[i];
+        return reduce_once(r);
+    }
+    DEVFN static E sqr(const E& a) { return mul(a, a); }
+    DEVFN static E to_mont(const E& canon) { return mul(canon, r2()); }
+    DEVFN static E from_mont(const E& a) { E o = zero(); o.l[0] = 1; return mul(a, o); }
+    DEVFN static E from_u32(uint32_t v) { E o = zero(); o.l[0] = v; return to_mont(o); }
+    // a^e, e given as 8 little-endian 32-bit limbs (uniform across lanes)
+    DEVNOINL static E pow(const E& a, const uint32_t* e) {
+        E acc = one();
+        bool started = false;
+        for (int i = 255; i >= 0; i--) {
+            if (started) acc = sqr(acc);
+            if ((e[i >> 5] >> (i & 31)) & 1) { acc = started ? mul(acc, a) : a; started = true; }
+        }
+        return acc;
+    }
+    // Fermat inverse a^(p-2); 0 -> 0
+    DEVFN static E inv(const E& a) {
+        uint32_t e[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = P::mod(i);
+        e[0] -= 2;
+        return pow(a, e);
+    }
+    // canonical value > (p-1)/2 ?   (input in Montgomery form)
+    DEVFN static bool lex_large(const E& a) {
+        E c = from_mont(a);
+        // compare with (p-1)/2
+        uint32_t h[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { uint32_t lo = P::mod(i) - (i == 0 ? 1u : 0u); uint32_t hi = i < 7 ? P::mod(i + 1) : 0u; h[i] = (lo >> 1) | (hi << 31); }
+        for (int i = 7; i >= 0; i--) { if (c.l[i] > h[i]) return true; if (c.l[i] < h[i]) return false; }
+        return false;
+    }
+};
+
+using Fp = Field<FpParams>;
+using Fr = Field<FrParams>;
+
+// ---- Fp2 = Fp[u]/(u^2+1) ----
+struct alignas(16) fe2 { fe a0, a1; };
+struct Fp2 {
+    using E = fe2;
+    DEVFN static E zero() { return E{Fp::zero(), Fp::zero()}; }
+    DEVFN static E one() { return E{Fp::one(), Fp::zero()}; }
+    DEVFN static bool is_zero(const E& a) { return Fp::is_zero(a.a0) && Fp::is_zero(a.a1); }
+    DEVFN static bool eq(const E& a, const E& b) { return Fp::eq(a.a0, b.a0) && Fp::eq(a.a1, b.a1); }
+    DEVFN static E add(const E& a, const E& b) { return E{Fp::add(a.a0, b.a0), Fp::add(a.a1, b.a1)}; }
+    DEVFN static E sub(const E& a, const E& b) { return E{Fp::sub(a.a0, b.a0), Fp::sub(a.a1, b.a1)}; }
+    DEVFN static E dbl(const E& a) { return add(a, a); }
+    DEVFN static E neg(const E& a) { return E{Fp::neg(a.a0), Fp::neg(a.a1)}; }
+    DEVFN static E mul(const E& a, const E& b) {
+        fe t0 = Fp::mul(a.a0, b.a0), t1 = Fp::mul(a.a1, b.a1);
+        fe t2 = Fp::mul(Fp::add(a.a0, a.a1), Fp::add(b.a0, b.a1));
+        return E{Fp::sub(t0, t1), Fp::sub(Fp::sub(t2, t0), t1)};
+    }
+    DEVFN static E sqr(const E& a) {
+        // (a0+a1)(a0-a1) + 2 a0 a1 u
+        fe s = Fp::add(a.a0, a.a1), d = Fp::sub(a.a0, a.a1), m = Fp::mul(a.a0, a.a1);
+        return E{Fp::mul(s, d), Fp::dbl(m)};
+    }
+    DEVFN static E inv(const E& a) {
+        fe n = Fp::add(Fp::sqr(a.a0), Fp::sqr(a.a1));
+        fe ni = Fp::inv(n);
+        return E{Fp::mul(a.a0, ni), Fp::neg(Fp::mul(a.a1, ni))};
+    }
+    DEVFN static bool lex_large(const E& a) { return Fp::is_zero(a.a1) ? Fp::lex_large(a.a0) : Fp::lex_large(a.a1); }
+};
+
+// ---- curve points, generic over the coordinate field F (Fp -> G1, Fp2 -> G2) ----
+template <class F>
+struct Aff { typename F::E x, y; };              // never the point at infinity (tables hold finite points)
+template <class F>
+struct Xyzz { typename F::E x, y, zz, zzz; };    // infinity <=> zz == 0
+
+template <class F>
+struct Curve {
+    using E = typename F::E;
+    using A = Aff<F>;
+    using X = Xyzz<F>;
+    DEVFN static X inf() { return X{F::zero(), F::zero(), F::zero(), F::zero()}; }
+    DEVFN static bool is_inf(const X& p) { return F::is_zero(p.zz); }
+    DEVFN static X from_aff(const A& a) { return X{a.x, a.y, F::one(), F::one()}; }
+    DEVNOINL static X dbl_slow(const X& p) { return dbl(p); }
+    DEVFN static X dbl(const X& p) {
+        if (is_inf(p)) return p;
+        E U = F::dbl(p.y), V = F::sqr(U), Wv = F::mul(U, V), S = F::mul(p.x, V);
+        E xx = F::sqr(p.x), M = F::add(F::dbl(xx), xx);
+        X r;
+        r.x = F::sub(F::sqr(M), F::dbl(S));
+        r.y = F::sub(F::mul(M, F::sub(S, r.x)), F::mul(Wv, p.y));
+        r.zz = F::mul(V, p.zz);
+        r.zzz = F::mul(Wv, p.zzz);
+        return r;
+    }
+    // p + q, q affine (finite)
+    DEVFN static X madd(const X& p, const A& q) {
+        if (is_inf(p)) return from_aff(q);
+        E U2 = F::mul(q.x, p.zz), S2 = F::mul(q.y, p.zzz);
+        E Pd = F::sub(U2, p.x), Rd = F::sub(S2, p.y);
+        if (F::is_zero(Pd)) {   // rare: same x — doubling or cancellation (kept out of line)
+            if (F::is_zero(Rd)) return dbl_slow(from_aff(q));
+            return inf();
+        }
+        E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(p.x, PP);
+        X r;
+        r.x = F::sub(F::sub(F::sqr(Rd), PPP), F::dbl(Q));
+        r.y = F::sub(F::mul(Rd, F::sub(Q, r.x)), F::mul(p.y, PPP));
+        r.zz = F::mul(p.zz, PP);
+        r.zzz = F::mul(p.zzz, PPP);
+        return r;
+    }
+    DEVFN static X add(const X& p, const X& q) {
+        if (is_inf(p)) return q;
+        if (is_inf(q)) return p;
+        E U1 = F::mul(p.x, q.zz), U2 = F::mul(q.x, p.zz);
+        E S1 = F::mul(p.y, q.zzz), S2 = F::mul(q.y, p.zzz);
+        E Pd = F::sub(U2, U1), Rd = F::sub(S2, S1);
+        if (F::is_zero(Pd)) {
+            if (F::is_zero(Rd)) return dbl_slow(p);
+            return inf();
+        }
+        E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(U1, PP);
+        X r;
+        r.x = F::sub(F::sub(F::sqr(Rd), PPP), F::dbl(Q));
+        r.y = F::sub(F::mul(Rd, F::sub(Q, r.x)), F::mul(S1, PPP));
+        r.zz = F::mul(F::mul(p.zz, q.zz), PP);
+        r.zzz = F::mul(F::mul(p.zzz, q.zzz), PPP);
+        return r;
+    }
+    DEVFN static A neg(const A& a) { return A{a.x, F::neg(a.y)}; }
+    // to affine; caller guarantees !is_inf.  1/ZZ = ZZ^2 / ZZZ^2  (ZZ^3 = ZZZ^2)
+    DEVFN static A to_aff(const X& p) {
+        E i = F::inv(p.zzz);
+        E i2 = F::sqr(i);
+        E izz = F::mul(F::sqr(p.zz), i2);
+        return A{F::mul(p.x, izz), F::mul(p.y, i)};
+    }
+};
+using G1 = Curve<Fp>;
+using G2 = Curve<Fp2>;
+
+// ---- global-memory helpers: a field element is 32 B = two 16-B vector accesses ----
+DEVFN fe load_fe(const fe* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    fe r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+DEVFN void store_fe(fe* p, const fe& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+}  // namespace bn254

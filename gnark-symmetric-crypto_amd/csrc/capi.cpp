@@ -1,0 +1,295 @@
+// C-ABI of libprove (see include/libprove.h) and the JSON host logic behind it.
+//
+// Mirrors, symbol for symbol, the reference's cgo exports (libraries/prover/libprove.go:17-47) and the
+// dispatch / JSON layer they call (libraries/prover/impl/prove_impl.go:65-143, provers.go:53-59, :79-89, :172-182):
+// algorithm registry, idempotent InitAlgorithm, Go-encoding/json-compatible input decoding, the
+// {"proof":{"proofJson"},"publicSignals"} output, and "panic -> JSON" error reporting.
+#include "../../include/libprove.h"
+#include "engine.hpp"
+#include "host_ciphers.hpp"
+#include "json.hpp"
+#include <sys/random.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace gsc;
+
+namespace {
+
+const char* kAlgorithmNames[3] = {"chacha20", "aes-128-ctr", "aes-256-ctr"};   // prove_impl.go:21-25
+
+std::mutex g_mu;
+std::unique_ptr<Algorithm> g_algo[3];
+bool g_fixed_rand = false; uint8_t g_r[32], g_s[32], g_mask[32];   // little-endian canonical
+DebugVectors g_debug;
+
+// Fr modulus, big-endian
+const uint8_t kFrModBE[32] = {0x30, 0x64, 0x4e, 0x72, 0xe1, 0x31, 0xa0, 0x29, 0xb8, 0x50, 0x45, 0xb6, 0x81, 0x81, 0x58, 0x5d,
+                              0x28, 0x33, 0xe8, 0x48, 0x79, 0xb9, 0x70, 0x91, 0x43, 0xe1, 0xf5, 0x93, 0xf0, 0x00, 0x00, 0x01};
+
+void random_fr_le(uint8_t out[32]) {   // uniform in [0, r) by rejection (fr.SetRandom in the reference)
+    for (;;) {
+        uint8_t be[32]; size_t got = 0;
+        while (got < 32) { ssize_t k = getrandom(be + got, 32 - got, 0); if (k > 0) got += (size_t)k; }
+        be[0] &= 0x3F;
+        if (memcmp(be, kFrModBE, 32) < 0) { for (int i = 0; i < 32; i++) out[i] = be[31 - i]; return; }
+    }
+}
+
+// A Go panic value, already rendered as the JSON that libprove.go:33-43 would return.
+struct GoPanic { std::string json; };
+[[noreturn]] void panic_string(const std::string& msg) { throw GoPanic{json_quote(msg)}; }
+
+int find_cipher(const std::string& name) { for (int i = 0; i < 3; i++) if (name == kAlgorithmNames[i]) return i; return -1; }
+
+bool ascii_fold_eq(const std::string& a, const char* b) {
+    size_t n = strlen(b); if (a.size() != n) return false;
+    for (size_t i = 0; i < n; i++) { char x = a[i], y = b[i]; if (x >= 'A' && x <= 'Z') x += 32; if (y >= 'A' && y <= 'Z') y += 32; if (x != y) return false; }
+    return true;
+}
+
+struct Decoded { std::string cipher; std::vector<uint8_t> key, nonce, input; uint32_t counter = 0; };
+
+// encoding/json semantics for InputParams (provers.go:53-59): case-insensitive keys, unknown keys ignored, the first
+// type error is remembered while decoding continues, []uint8 from base64 string / null / array of 0..255.
+struct TypeError { bool set = false; std::string json; };
+void type_error(TypeError& te, const std::string& value, size_t offset, const char* field) {
+    if (te.set) return;
+    te.set = true;
+    te.json = "{\"Value\":" + json_quote(value) + ",\"Type\":{},\"Offset\":" + std::to_string(offset) + ",\"Struct\":\"InputParams\",\"Field\":" + json_quote(field) + "}";
+}
+size_t go_offset(const JsonValue& v) { return (v.kind == JsonValue::Array || v.kind == JsonValue::Object) ? v.start + 1 : v.offset; }
+
+void decode_bytes(const JsonValue& v, std::vector<uint8_t>& out, TypeError& te, const char* field) {
+    switch (v.kind) {
+        case JsonValue::Null: out.clear(); return;
+        case JsonValue::String: {
+            size_t bad = 0; std::vector<uint8_t> tmp;
+            if (!base64_decode(v.text, tmp, bad)) throw GoPanic{std::to_string(bad)};   // base64.CorruptInputError is an int64
+            out = std::move(tmp); return;
+        }
+        case JsonValue::Array: {
+            std::vector<uint8_t> tmp;
+            for (const JsonValue& e : v.items) {
+                uint8_t b = 0;
+                if (e.kind == JsonValue::Number) {
+                    const std::string& t = e.text; bool ok = !t.empty() && t.find_first_not_of("0123456789") == std::string::npos && t.size() <= 3;
+                    unsigned val = ok ? (unsigned)atoi(t.c_str()) : 256;
+                    if (val > 255) type_error(te, "number " + t, e.offset, field); else b = (uint8_t)val;
+                } else if (e.kind != JsonValue::Null) type_error(te, e.go_kind(), go_offset(e), field);
+                tmp.push_back(b);
+            }
+            out = std::move(tmp); return;
+        }
+        default: type_error(te, v.go_kind(), go_offset(v), field); return;
+    }
+}
+
+Decoded decode_params(const JsonValue& root) {
+    Decoded d; TypeError te;
+    if (root.kind == JsonValue::Null) panic_string("runtime error: invalid memory address or nil pointer dereference");
+    if (root.kind != JsonValue::Object) { type_error(te, root.go_kind(), go_offset(root), ""); 
+        // Go reports Struct/Field empty for a top-level mismatch
+        throw GoPanic{"{\"Value\":" + json_quote(root.go_kind()) + ",\"Type\":{},\"Offset\":" + std::to_string(go_offset(root)) + ",\"Struct\":\"\",\"Field\":\"\"}"}; }
+    for (const auto& kv : root.members) {
+        const JsonValue& v = kv.second;
+        if (ascii_fold_eq(kv.first, "cipher")) {
+            if (v.kind == JsonValue::String) d.cipher = v.text; else if (v.kind != JsonValue::Null) type_error(te, v.go_kind(), go_offset(v), "cipher");
+        } else if (ascii_fold_eq(kv.first, "key")) decode_bytes(v, d.key, te, "key");
+        else if (ascii_fold_eq(kv.first, "nonce")) decode_bytes(v, d.nonce, te, "nonce");
+        else if (ascii_fold_eq(kv.first, "input")) decode_bytes(v, d.input, te, "input");
+        else if (ascii_fold_eq(kv.first, "counter")) {
+            if (v.kind == JsonValue::Number) {
+                const std::string& t = v.text; bool ok = !t.empty() && t.find_first_not_of("0123456789") == std::string::npos && t.size() <= 10;
+                unsigned long long val = ok ? strtoull(t.c_str(), nullptr, 10) : ~0ull;
+                if (!ok || val > 0xFFFFFFFFull) type_error(te, "number " + t, v.offset, "counter"); else d.counter = (uint32_t)val;
+            } else if (v.kind != JsonValue::Null) type_error(te, v.go_kind(), go_offset(v), "counter");
+        }
+    }
+    if (te.set) throw GoPanic{te.json};
+    return d;
+}
+
+// length checks of provers.go:81-89 / :174-182 (log.Panicf -> string panic), then the native cipher
+ProofRequest make_request(int cipher, const Decoded& d) {
+    ProofRequest q; memset(&q, 0, sizeof q);
+    if (cipher == CHACHA20) { if (d.key.size() != 32) panic_string("key length must be 32: " + std::to_string(d.key.size())); }
+    else if (d.key.size() != 32 && d.key.size() != 16) panic_string("key length must be 16 or 32: " + std::to_string(d.key.size()));
+    if (d.nonce.size() != 12) panic_string("nonce length must be 12: " + std::to_string(d.nonce.size()));
+    if (d.input.size() != 64) panic_string("plaintext length must be 64: " + std::to_string(d.input.size()));
+    if (cipher != CHACHA20 && d.key.size() != (cipher == AES_128 ? 16u : 32u)) throw GoPanic{"{}"};   // frontend.NewWitness schema mismatch: an error value with no exported fields
+    q.keylen = (uint32_t)d.key.size(); memcpy(q.key, d.key.data(), d.key.size());
+    memcpy(q.nonce, d.nonce.data(), 12); q.counter = d.counter; memcpy(q.plaintext, d.input.data(), 64);
+    if (cipher == CHACHA20) chacha20_xor_stream(q.key, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
+    else aes_ctr_xor_stream(q.key, q.keylen, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
+    return q;
+}
+void fill_randomness(ProofRequest& q) {
+    if (g_fixed_rand) { memcpy(q.r, g_r, 32); memcpy(q.s, g_s, 32); memcpy(q.mask, g_mask, 32); }
+    else { random_fr_le(q.r); random_fr_le(q.s); random_fr_le(q.mask); }
+}
+
+Algorithm* lookup(int cipher) { std::lock_guard<std::mutex> l(g_mu); return g_algo[cipher].get(); }
+
+std::string success_json(const ProofResult& r, const uint8_t ct[64]) {   // OutputParams, prove_impl.go:45-52
+    return "{\"proof\":{\"proofJson\":\"" + base64_encode(r.proof, r.proof_len) + "\"},\"publicSignals\":\"" + base64_encode(ct, 64) + "\"}";
+}
+
+// parses + validates one request; throws GoPanic
+struct Prepared { int cipher; ProofRequest req; };
+Prepared prepare(const JsonValue& v) {
+    Decoded d = decode_params(v);
+    const int cipher = find_cipher(d.cipher);
+    if (cipher < 0) panic_string("could not find prover for" + d.cipher);                       // prove_impl.go:141 (sic: no space)
+    if (!lookup(cipher)) panic_string("proving params are not initialized for cipher: " + d.cipher);   // :124-126
+    Prepared p{cipher, make_request(cipher, d)};
+    fill_randomness(p.req);
+    return p;
+}
+
+struct Prove_return to_c(const std::string& s) {
+    void* buf = malloc(s.size() ? s.size() : 1);           // C.CBytes
+    if (!buf) return {nullptr, 0};
+    memcpy(buf, s.data(), s.size());
+    return {buf, (GoInt)s.size()};
+}
+
+std::string prove_one_json(const char* data, size_t len, DebugVectors* dbg) {
+    try {
+        JsonValue root;
+        try { root = json_parse(data, len); } catch (const JsonSyntaxError& e) { throw GoPanic{"{\"Offset\":" + std::to_string(e.offset) + "}"}; }
+        Prepared p = prepare(root);
+        ProofResult res;
+        lookup(p.cipher)->prove_batch(&p.req, 1, &res, dbg);
+        if (res.status) throw GoPanic{"{}"};     // gnark solver / prover error: no exported fields
+        return success_json(res, p.req.ciphertext);
+    } catch (const GoPanic& g) {
+        printf("%s\n", g.json.c_str());        // libprove.go:35 prints the panic value
+        return g.json;
+    } catch (const std::exception& e) {
+        printf("%s\n", e.what());
+        return json_quote(e.what());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void enforce_binding(void) {}
+
+GoUint8 InitAlgorithm(GoUint8 algorithmID, GoSlice provingKey, GoSlice r1cs) {
+    if (algorithmID > 2) return 0;                               // unknown id -> false (prove_impl.go:113)
+    std::lock_guard<std::mutex> l(g_mu);
+    if (g_algo[algorithmID]) return 1;                           // already initialised (prove_impl.go:74-76)
+    try {
+        if (!provingKey.data || provingKey.len <= 0 || !r1cs.data || r1cs.len <= 0) throw std::runtime_error("error reading proving key: EOF");
+        g_algo[algorithmID].reset(new Algorithm((Cipher)algorithmID, (const uint8_t*)provingKey.data, (size_t)provingKey.len,
+                                                (const uint8_t*)r1cs.data, (size_t)r1cs.len, config_from_env()));
+        return 1;
+    } catch (const std::exception& e) {
+        printf("%s\n", e.what());                                 // fmt.Println(err) in the reference
+        return 0;
+    }
+}
+
+void Free(void* pointer) { free(pointer); }
+
+struct Prove_return Prove(GoSlice params) {
+    return to_c(prove_one_json((const char*)params.data, params.len > 0 ? (size_t)params.len : 0, nullptr));
+}
+
+struct Prove_return ProveBatch(GoSlice params) {
+    std::string out;
+    try {
+        JsonValue root;
+        try { root = json_parse((const char*)params.data, params.len > 0 ? (size_t)params.len : 0); }
+        catch (const JsonSyntaxError& e) { throw GoPanic{"{\"Offset\":" + std::to_string(e.offset) + "}"}; }
+        if (root.kind != JsonValue::Array) throw GoPanic{json_quote("ProveBatch expects a JSON array")};
+        const size_t n = root.items.size();
+        std::vector<std::string> results(n);
+        std::vector<Prepared> ok; std::vector<size_t> where;
+        for (size_t i = 0; i < n; i++) {
+            try { ok.push_back(prepare(root.items[i])); where.push_back(i); }
+            catch (const GoPanic& g) { results[i] = g.json; }
+        }
+        for (int c = 0; c < 3; c++) {                              // one device batch per algorithm
+            std::vector<ProofRequest> reqs; std::vector<size_t> idx;
+            for (size_t k = 0; k < ok.size(); k++) if (ok[k].cipher == c) { reqs.push_back(ok[k].req); idx.push_back(where[k]); }
+            if (reqs.empty()) continue;
+            std::vector<ProofResult> res(reqs.size());
+            lookup(c)->prove_batch(reqs.data(), reqs.size(), res.data());
+            for (size_t k = 0; k < reqs.size(); k++) results[idx[k]] = res[k].status ? std::string("{}") : success_json(res[k], reqs[k].ciphertext);
+        }
+        out = "[";
+        for (size_t i = 0; i < n; i++) { if (i) out += ","; out += results[i]; }
+        out += "]";
+    } catch (const GoPanic& g) { out = g.json; }
+    catch (const std::exception& e) { out = json_quote(e.what()); }
+    return to_c(out);
+}
+
+long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t* proofs, uint32_t* proof_lens, uint8_t* ciphertexts) {
+    if (cipher > 2) return -1;
+    Algorithm* a = lookup(cipher);
+    if (!a) return -1;
+    try {
+        std::vector<ProofRequest> reqs(n); std::vector<ProofResult> res(n);
+        for (size_t i = 0; i < n; i++) {
+            const uint8_t* rec = inputs + 112 * i; ProofRequest& q = reqs[i]; memset(&q, 0, sizeof q);
+            q.keylen = cipher == AES_128 ? 16 : 32; memcpy(q.key, rec, q.keylen); memcpy(q.nonce, rec + 32, 12);
+            q.counter = (uint32_t)rec[44] | ((uint32_t)rec[45] << 8) | ((uint32_t)rec[46] << 16) | ((uint32_t)rec[47] << 24);
+            memcpy(q.plaintext, rec + 48, 64);
+            if (cipher == CHACHA20) chacha20_xor_stream(q.key, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
+            else aes_ctr_xor_stream(q.key, q.keylen, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
+            fill_randomness(q);
+        }
+        a->prove_batch(reqs.data(), n, res.data());
+        long long good = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (ciphertexts) memcpy(ciphertexts + 64 * i, reqs[i].ciphertext, 64);
+            proof_lens[i] = res[i].status ? 0u : (uint32_t)res[i].proof_len;
+            memset(proofs + 196 * i, 0, 196);
+            if (!res[i].status) { memcpy(proofs + 196 * i, res[i].proof, res[i].proof_len); good++; }
+        }
+        return good;
+    } catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
+}
+
+void gsc_set_deterministic_randomness(const uint8_t* r_be32, const uint8_t* s_be32, const uint8_t* mask_be32) {
+    std::lock_guard<std::mutex> l(g_mu);
+    if (!r_be32 || !s_be32) { g_fixed_rand = false; return; }
+    for (int i = 0; i < 32; i++) { g_r[i] = r_be32[31 - i]; g_s[i] = s_be32[31 - i]; g_mask[i] = mask_be32 ? mask_be32[31 - i] : 0; }
+    g_fixed_rand = true;
+}
+
+long long gsc_debug_prove(GoSlice params) {
+    g_debug = DebugVectors();
+    std::string r = prove_one_json((const char*)params.data, params.len > 0 ? (size_t)params.len : 0, &g_debug);
+    return r.find("\"proof\"") != std::string::npos ? 0 : -1;
+}
+long long gsc_debug_vector(int which, uint8_t* out, size_t cap) {
+    const std::vector<uint8_t>* v = which == 0 ? &g_debug.W : which == 1 ? &g_debug.A : which == 2 ? &g_debug.B : which == 3 ? &g_debug.C : which == 4 ? &g_debug.H : nullptr;
+    if (!v || v->empty()) return -1;
+    if (out) memcpy(out, v->data(), cap < v->size() ? cap : v->size());
+    return (long long)(v->size() / 32);
+}
+
+size_t gsc_describe(GoUint8 algorithmID, char* out, size_t cap) {
+    if (algorithmID > 2 || !cap) return 0;
+    Algorithm* a = lookup(algorithmID);
+    std::string s = a ? a->describe() : std::string("not initialised");
+    size_t n = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(out, s.data(), n); out[n] = 0; return n;
+}
+int gsc_last_stage_ms(GoUint8 algorithmID, float out[4]) {
+    if (algorithmID > 2) return -1;
+    Algorithm* a = lookup(algorithmID); if (!a) return -1;
+    a->last_stage_ms(out); return 0;
+}
+
+}  // extern "C"

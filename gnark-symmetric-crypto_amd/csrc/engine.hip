@@ -1,0 +1,348 @@
+// GPU prover engine: InitAlgorithm-time upload / table build and the per-batch device pipeline.
+// See engine.hpp for the reference interface this mirrors.
+#include "engine.hpp"
+#include "formats.hpp"
+#include "kernels.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+
+namespace gsc {
+
+#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; if (count) HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T))); }
+    void upload(const T* src, size_t count, hipStream_t s) { HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s)); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+
+// Montgomery images of 0, 1, 2, -1, -2 in Fr: gnark puts these at coefficient ids 0..4 of every R1CS
+// (SURVEY.md App. A); the solver kernel short-cuts them to additions.
+const uint32_t kSmallCoeffs[5][8] = {
+    {0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u},
+    {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u},
+    {0x9ffffff6u, 0x592c6838u, 0x3ec19a53u, 0x6df8ed2bu, 0xf0f28c5cu, 0xccdd46deu, 0x340fbe5eu, 0x1c14ef83u},
+    {0xa0000006u, 0x974bc177u, 0xda58a367u, 0xf13771b2u, 0x0908122eu, 0x51e1a247u, 0x4729c0fau, 0x2259d6b1u},
+    {0x5000000bu, 0xeab58d5bu, 0x3af7d63du, 0xba3afb1du, 0x908ecc00u, 0xeb72fed7u, 0xad21e1cau, 0x144f5eefu},
+};
+// (p-1)/2, big-endian: a compressed point carries the "larger y" flag iff y > (p-1)/2
+const uint8_t kHalfP[32] = {0x18, 0x32, 0x27, 0x39, 0x70, 0x98, 0xd0, 0x14, 0xdc, 0x28, 0x22, 0xdb, 0x40, 0xc0, 0xac, 0x2e,
+                            0xcb, 0xc0, 0xb5, 0x48, 0xb4, 0x38, 0xe5, 0x46, 0x9e, 0x10, 0x46, 0x0b, 0x6c, 0x3e, 0x7e, 0xa3};
+
+void le_limbs_to_be(const uint8_t* le, uint8_t* be) { for (int i = 0; i < 32; i++) be[i] = le[31 - i]; }
+bool be_greater(const uint8_t* a, const uint8_t* b) { int c = memcmp(a, b, 32); return c > 0; }
+bool be_is_zero(const uint8_t* a) { for (int i = 0; i < 32; i++) if (a[i]) return false; return true; }
+
+template <class AffT>
+struct MsmSet {                     // one fixed-base MSM: tables + scalar row map
+    DevBuf<AffT> table; DevBuf<uint32_t> rows; size_t nbases = 0; int c = 0, nwin = 0; size_t nslices = 0;
+};
+
+}  // namespace
+
+EngineConfig config_from_env() {
+    EngineConfig c;
+    c.device = env_int("GSC_DEVICE", 0);
+    c.max_batch = (size_t)env_int("GSC_MAX_BATCH", 1024);
+    c.window_z = env_int("GSC_WINDOW_Z", 10);
+    c.window_w = env_int("GSC_WINDOW_W", 8);
+    if (c.max_batch < 64) c.max_batch = 64;
+    c.max_batch = (c.max_batch + 63) / 64 * 64;
+    if (c.window_z < 2 || c.window_z > 16 || c.window_w < 2 || c.window_w > 16) throw std::runtime_error("GSC_WINDOW_* must be in [2,16]");
+    return c;
+}
+
+class AlgorithmImpl {
+  public:
+    Cipher cipher; EngineConfig cfg;
+    size_t n_wires = 0, n_public = 0, n_constraints = 0, domain_n = 0; int L = 0;
+    bool has_commitment = false;
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {};
+    float stage_ms[4] = {0, 0, 0, 0};
+    size_t table_bytes = 0;
+
+    // program
+    DevBuf<uint32_t> prog, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
+    size_t split_word = 0;
+    // NTT
+    DevBuf<fe> tw_fwd, tw_inv, scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
+    // MSM sets
+    MsmSet<G1Aff> mA, mB1, mK, mZ; MsmSet<G2Aff> mB2;
+    // batch buffers
+    size_t cap = 0;
+    DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags; DevBuf<uint32_t> d_status;
+    DevBuf<fe> d_W, d_A, d_B, d_C;
+    DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
+
+    AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf) : cipher(c), cfg(cf) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the GPU prover has no CPU fallback");
+        HIP_CHECK(hipSetDevice(cfg.device));
+        HIP_CHECK(hipStreamCreate(&stream));
+        for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+        R1csFile cs = parse_r1cs(r1cs, r1cs_len);
+        PkFile key = parse_pk(pk, pk_len);
+        init_program(cs);
+        init_key(cs, key);
+        alloc_batch(cfg.max_batch);
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    ~AlgorithmImpl() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
+
+    void init_program(const R1csFile& cs) {
+        n_wires = cs.n_wires(); n_public = cs.n_public; n_constraints = cs.n_constraints; has_commitment = cs.has_commitment;
+        const size_t expect_in = cipher == CHACHA20 ? 1408 : cipher == AES_128 ? 157 : 173;
+        if (cs.n_public - 1 + cs.n_secret != expect_in) throw std::runtime_error("r1cs: witness size does not match the cipher's circuit");
+        if (cs.n_coeff() < 5 || memcmp(cs.coeff_limbs.data(), kSmallCoeffs, sizeof kSmallCoeffs)) throw std::runtime_error("r1cs: coefficient ids 0..4 are not 0,1,2,-1,-2");
+        SolverProgram sp = build_solver_program(cs);
+        split_word = sp.split_word;
+        prog.alloc(sp.words.size()); prog.upload(sp.words.data(), sp.words.size(), stream);
+        lookup_coeff.alloc(sp.lookup_coeff.size() ? sp.lookup_coeff.size() : 1);
+        if (!sp.lookup_coeff.empty()) lookup_coeff.upload(sp.lookup_coeff.data(), sp.lookup_coeff.size(), stream);
+        coeff.alloc(cs.n_coeff()); coeff_inv.alloc(cs.n_coeff());
+        HIP_CHECK(hipMemcpyAsync(coeff.p, cs.coeff_limbs.data(), cs.coeff_limbs.size() * 4, hipMemcpyHostToDevice, stream));
+        launch_fr_inverse(coeff.p, coeff_inv.p, cs.n_coeff(), stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    // decompress `raw` (count points of `sz` bytes) into out[offset...]; returns per-point status
+    std::vector<uint8_t> decompress_g1(const std::vector<uint8_t>& raw, G1Aff* out) {
+        const size_t n = raw.size() / 32; std::vector<uint8_t> st(n);
+        if (!n) return st;
+        DevBuf<uint8_t> d_raw(raw.size()), d_st(n);
+        d_raw.upload(raw.data(), raw.size(), stream);
+        launch_decompress_g1(d_raw.p, out, d_st.p, n, stream);
+        HIP_CHECK(hipMemcpyAsync(st.data(), d_st.p, n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return st;
+    }
+    std::vector<uint8_t> decompress_g2(const std::vector<uint8_t>& raw, G2Aff* out) {
+        const size_t n = raw.size() / 64; std::vector<uint8_t> st(n);
+        if (!n) return st;
+        DevBuf<uint8_t> d_raw(raw.size()), d_st(n);
+        d_raw.upload(raw.data(), raw.size(), stream);
+        launch_decompress_g2(d_raw.p, out, d_st.p, n, stream);
+        HIP_CHECK(hipMemcpyAsync(st.data(), d_st.p, n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return st;
+    }
+
+    template <class AffT, class Decomp, class Build>
+    void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build) {
+        const size_t n = raw.size() / point_bytes;
+        if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
+        DevBuf<AffT> bases(n ? n : 1);
+        std::vector<uint8_t> st = decomp(raw, bases.p);
+        for (size_t i = 0; i < n; i++) {
+            if (st[i] == 1) throw std::runtime_error(std::string("pk: invalid point in ") + what);
+            if (st[i] == 2) rows[i] = (uint32_t)(n_wires + 3);          // point at infinity: never selected
+        }
+        set.nbases = n; set.c = c; set.nwin = (254 + c - 1) / c;
+        set.nslices = (n + 63) / 64; if (!set.nslices) set.nslices = 1;
+        const size_t D = (size_t)1 << (c - 1);
+        set.table.alloc(n * set.nwin * D ? n * set.nwin * D : 1);
+        table_bytes += set.table.bytes();
+        set.rows.alloc(n ? n : 1); if (n) set.rows.upload(rows.data(), n, stream);
+        build(bases.p, n, c, set.nwin, set.table.p);
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    void init_key(const R1csFile& cs, const PkFile& key) {
+        if (key.n_wires != n_wires) throw std::runtime_error("pk: wire count does not match the r1cs");
+        domain_n = key.domain_n; L = 0; while (((size_t)1 << L) < domain_n) L++;
+        if (domain_n < n_constraints || L < 4 || L > 24) throw std::runtime_error("pk: domain too small for the constraint system");
+        if (cs.has_commitment != key.has_commitment_key) throw std::runtime_error("pk: commitment keys do not match the r1cs");
+        if (cs.has_commitment) throw std::runtime_error("commitment (AES-V2) circuits: device path not wired yet");
+        // NTT constants
+        {
+            uint8_t be[5 * 32];
+            memcpy(be, key.omega, 32); memcpy(be + 32, key.omega_inv, 32); memcpy(be + 64, key.coset_g, 32); memcpy(be + 96, key.coset_g_inv, 32); memcpy(be + 128, key.n_inv, 32);
+            DevBuf<uint8_t> d_be(sizeof be); d_be.upload(be, sizeof be, stream);
+            dom.alloc(6);
+            launch_fr_from_be(d_be.p, dom.p, 5, stream);
+            tw_fwd.alloc(domain_n / 2); tw_inv.alloc(domain_n / 2); scale_mid.alloc(domain_n); scale_out.alloc(domain_n);
+            launch_ntt_constants(dom.p, dom.p + 1, dom.p + 2, dom.p + 3, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, stream);
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        auto cat = [](std::vector<uint8_t> a, std::initializer_list<const std::vector<uint8_t>*> more) { for (auto* m : more) a.insert(a.end(), m->begin(), m->end()); return a; };
+        const uint32_t ROW_ONE = 0, ROW_R = (uint32_t)n_wires, ROW_S = ROW_R + 1, ROW_NRS = ROW_R + 2;
+        std::vector<uint32_t> rowsA, rowsB, rowsK;
+        for (size_t i = 0; i < n_wires; i++) { if (!key.inf_A[i]) rowsA.push_back((uint32_t)i); if (!key.inf_B[i]) rowsB.push_back((uint32_t)i); }
+        {
+            std::vector<uint8_t> skip(n_wires, 0);
+            if (cs.has_commitment) { for (uint32_t w : cs.commit_private) skip[w] = 1; skip[cs.commit_wire] = 1; }
+            for (size_t i = cs.n_public; i < n_wires; i++) if (!skip[i]) rowsK.push_back((uint32_t)i);
+            if (rowsK.size() * 32 != key.g1_K.size()) throw std::runtime_error("pk: G1.K size does not match the private wires");
+        }
+        rowsA.push_back(ROW_ONE); rowsA.push_back(ROW_R);
+        std::vector<uint32_t> rowsB2 = rowsB;
+        rowsB.push_back(ROW_ONE); rowsB.push_back(ROW_S); rowsB2.push_back(ROW_ONE); rowsB2.push_back(ROW_S);
+        rowsK.push_back(ROW_NRS);
+        std::vector<uint32_t> rowsZ(domain_n - 1); for (size_t i = 0; i < rowsZ.size(); i++) rowsZ[i] = (uint32_t)i;
+        auto dec1 = [this](const std::vector<uint8_t>& raw, G1Aff* out) { return decompress_g1(raw, out); };
+        auto dec2 = [this](const std::vector<uint8_t>& raw, G2Aff* out) { return decompress_g2(raw, out); };
+        auto bld1 = [this](const G1Aff* b, size_t n, int c, int nwin, G1Aff* t) { launch_build_table_g1(b, n, c, nwin, t, stream); };
+        auto bld2 = [this](const G2Aff* b, size_t n, int c, int nwin, G2Aff* t) { launch_build_table_g2(b, n, c, nwin, t, stream); };
+        build_set(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, bld1);
+        build_set(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, bld1);
+        build_set(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, bld1);
+        build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1);
+        build_set(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, bld2);
+    }
+
+    void alloc_batch(size_t B) {
+        cap = B;
+        d_inputs.alloc(176 * B); d_rs.alloc(64 * B); d_out.alloc(256 * B); d_flags.alloc((B + 3) / 4 * 4); d_status.alloc(B);
+        d_W.alloc((n_wires + 4) * B); d_A.alloc(domain_n * B); d_B.alloc(domain_n * B); d_C.alloc(domain_n * B);
+        size_t s1 = mA.nslices; for (size_t v : {mB1.nslices, mK.nslices, mZ.nslices}) if (v > s1) s1 = v;
+        d_part1a.alloc(s1 * B); d_part1b.alloc((s1 + 63) / 64 * B);
+        d_part2a.alloc(mB2.nslices * B); d_part2b.alloc((mB2.nslices + 63) / 64 * B);
+        d_sumA.alloc(B); d_sumB1.alloc(B); d_sumK.alloc(B); d_sumZ.alloc(B); d_sumB2.alloc(B); d_tmp.alloc(2 * B);
+    }
+
+    void run_msm_g1(const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum) {
+        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, set.nslices, d_part1a.p};
+        launch_msm_g1(a, stream);
+        G1Xyzz* src = d_part1a.p; G1Xyzz* alt = d_part1b.p; size_t ns = set.nslices;
+        for (;;) {
+            const size_t groups = (ns + 63) / 64;
+            G1Xyzz* dst = groups == 1 ? sum : alt;
+            launch_msm_reduce_g1(src, ns, B, dst, stream);
+            if (groups == 1) break;
+            G1Xyzz* t = src; src = dst; alt = t; ns = groups;
+        }
+    }
+    void run_msm_g2(const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
+        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, set.nslices, d_part2a.p};
+        launch_msm_g2(a, stream);
+        G2Xyzz* src = d_part2a.p; G2Xyzz* alt = d_part2b.p; size_t ns = set.nslices;
+        for (;;) {
+            const size_t groups = (ns + 63) / 64;
+            G2Xyzz* dst = groups == 1 ? sum : alt;
+            launch_msm_reduce_g2(src, ns, B, dst, stream);
+            if (groups == 1) break;
+            G2Xyzz* t = src; src = dst; alt = t; ns = groups;
+        }
+    }
+
+    void fetch_column(const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
+        out.resize(rows * 32);
+        HIP_CHECK(hipMemcpy2DAsync(out.data(), 32, reinterpret_cast<const uint8_t*>(mat) + 32 * col, B * 32, 32, rows, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    void prove_chunk(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg) {
+        const size_t B = (n + 63) / 64 * 64;
+        std::vector<uint8_t> h_in(176 * B), h_rs(64 * B);
+        for (size_t i = 0; i < B; i++) {
+            const ProofRequest& q = reqs[i < n ? i : n - 1];
+            uint8_t* rec = h_in.data() + 176 * i;
+            memset(rec, 0, 32); memcpy(rec, q.key, q.keylen);
+            memcpy(rec + 32, q.nonce, 12);
+            rec[44] = (uint8_t)q.counter; rec[45] = (uint8_t)(q.counter >> 8); rec[46] = (uint8_t)(q.counter >> 16); rec[47] = (uint8_t)(q.counter >> 24);
+            memcpy(rec + 48, q.plaintext, 64); memcpy(rec + 112, q.ciphertext, 64);
+            memcpy(h_rs.data() + 64 * i, q.r, 32); memcpy(h_rs.data() + 64 * i + 32, q.s, 32);
+        }
+        d_inputs.upload(h_in.data(), h_in.size(), stream);
+        d_rs.upload(h_rs.data(), h_rs.size(), stream);
+        HIP_CHECK(hipMemsetAsync(d_flags.p, 0, d_flags.bytes(), stream));
+        HIP_CHECK(hipEventRecord(ev[0], stream));
+        // 1. witness
+        if (cipher == CHACHA20) launch_assign_chacha(d_inputs.p, d_W.p, B, stream);
+        else launch_assign_aes(d_inputs.p, cipher == AES_128 ? 16 : 32, d_W.p, B, stream);
+        launch_prep_rs(d_rs.p, d_W.p, n_wires, B, stream);
+        SolverArgs sa{prog.p, 0, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p, nullptr, nullptr, 0};
+        launch_solver(sa, stream);
+        HIP_CHECK(hipEventRecord(ev[1], stream));
+        if (dbg) {
+            dbg->n_wires = n_wires; dbg->n_constraints = n_constraints; dbg->n = domain_n;
+            fetch_column(d_W.p, n_wires, B, 0, dbg->W); fetch_column(d_A.p, n_constraints, B, 0, dbg->A);
+            fetch_column(d_B.p, n_constraints, B, 0, dbg->B); fetch_column(d_C.p, n_constraints, B, 0, dbg->C);
+        }
+        // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
+        NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5};
+        launch_compute_h(plan, d_A.p, d_B.p, d_C.p, n_constraints, B, stream);
+        HIP_CHECK(hipEventRecord(ev[2], stream));
+        if (dbg) fetch_column(d_A.p, domain_n, B, 0, dbg->H);
+        // 3. MSMs
+        run_msm_g1(mA, d_W.p, 1, B, d_sumA.p);
+        run_msm_g1(mB1, d_W.p, 1, B, d_sumB1.p);
+        run_msm_g2(mB2, d_W.p, 1, B, d_sumB2.p);
+        run_msm_g1(mK, d_W.p, 1, B, d_sumK.p);
+        run_msm_g1(mZ, d_A.p, 0, B, d_sumZ.p);
+        HIP_CHECK(hipEventRecord(ev[3], stream));
+        // 4. assembly
+        launch_finalize(d_sumA.p, d_sumB1.p, d_sumB2.p, d_sumK.p, d_sumZ.p, d_rs.p, B, d_out.p, d_flags.p, d_tmp.p, stream);
+        HIP_CHECK(hipEventRecord(ev[4], stream));
+        std::vector<uint8_t> h_out(256 * B), h_flags(d_flags.n); std::vector<uint32_t> h_status(B);
+        HIP_CHECK(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_flags.data(), d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, B * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]); stage_ms[k] = ms; }
+        for (size_t i = 0; i < n; i++) serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], results[i]);
+    }
+
+    // gnark proof.WriteTo: Ar | Bs | Krs compressed, u32be nbCommitments, commitments, CommitmentPok
+    void serialize(const uint8_t* o, uint8_t flags, uint32_t status, ProofResult& res) const {
+        res.proof_len = 0; res.status = 0;
+        if (status) { res.status = 1; return; }
+        if (flags) { res.status = 2; return; }
+        uint8_t* p = res.proof;
+        auto g1 = [&](const uint8_t* xy, uint8_t* dst) {
+            uint8_t y[32]; le_limbs_to_be(xy, dst); le_limbs_to_be(xy + 32, y);
+            dst[0] |= be_greater(y, kHalfP) ? 0xC0 : 0x80;
+        };
+        g1(o, p);
+        {   // G2: X.A1 | X.A0, flag from y (A1 unless zero, then A0)
+            uint8_t y0[32], y1[32];
+            le_limbs_to_be(o + 96, p + 32); le_limbs_to_be(o + 64, p + 64);
+            le_limbs_to_be(o + 128, y0); le_limbs_to_be(o + 160, y1);
+            const bool large = be_is_zero(y1) ? be_greater(y0, kHalfP) : be_greater(y1, kHalfP);
+            p[32] |= large ? 0xC0 : 0x80;
+        }
+        g1(o + 192, p + 96);
+        p[128] = p[129] = p[130] = p[131] = 0;          // no commitments (ChaCha20-V3)
+        memset(p + 132, 0, 32); p[132] = 0x40;          // CommitmentPok = point at infinity
+        res.proof_len = 164;
+    }
+};
+
+Algorithm::Algorithm(Cipher cipher, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cfg)
+    : impl_(new AlgorithmImpl(cipher, pk, pk_len, r1cs, r1cs_len, cfg)) {}
+Algorithm::~Algorithm() = default;
+Cipher Algorithm::cipher() const { return impl_->cipher; }
+size_t Algorithm::max_batch() const { return impl_->cap; }
+void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impl_->stage_ms[i]; }
+std::string Algorithm::describe() const {
+    char buf[512];
+    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu",
+             impl_->n_wires, impl_->n_constraints, impl_->L, impl_->cap, impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
+             impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases);
+    return buf;
+}
+void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    HIP_CHECK(hipSetDevice(impl_->cfg.device));
+    for (size_t off = 0; off < n; off += impl_->cap) {
+        const size_t take = n - off < impl_->cap ? n - off : impl_->cap;
+        impl_->prove_chunk(reqs + off, take, results + off, off == 0 ? debug_first : nullptr);
+    }
+}
+
+}  // namespace gsc

@@ -1,0 +1,57 @@
+// Per-algorithm GPU prover state and the batch pipeline.
+//
+// Host-side mirror of the reference's per-cipher prover objects (libraries/prover/impl/provers.go:61-77:
+// Prover interface, baseProver{r1cs, pk}) — here "SetParams" uploads the decoded key and the solver program
+// to HBM and builds the fixed-base tables; "Prove" runs the device pipeline for a batch of independent proofs.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace gsc {
+
+enum Cipher : int { CHACHA20 = 0, AES_128 = 1, AES_256 = 2 };   // prove_impl.go:15-19
+
+struct ProofRequest {
+    uint8_t key[32]; uint32_t keylen;
+    uint8_t nonce[12]; uint32_t counter;
+    uint8_t plaintext[64];
+    uint8_t ciphertext[64];          // filled by the caller with the native cipher
+    uint8_t r[32], s[32], mask[32];  // prover randomness, canonical little-endian, < r
+};
+struct ProofResult {
+    int status = 0;                  // 0 ok; 1 unsatisfied constraint system; 2 degenerate point
+    uint8_t proof[196]; size_t proof_len = 0;   // gnark proof.WriteTo bytes
+};
+
+struct EngineConfig {
+    int device = 0;
+    size_t max_batch = 1024;     // proofs in flight per launch sequence (rounded to a multiple of 64)
+    int window_z = 10;           // digit width of the Z (quotient) tables
+    int window_w = 8;            // digit width of the A / B1 / B2 / K tables
+};
+EngineConfig config_from_env();
+
+// what: 0 W (Montgomery), 1 A, 2 B, 3 C (Montgomery; valid until computeH overwrites them: only with keep_abc), 4 h (canonical, bit-reversed order)
+struct DebugVectors { std::vector<uint8_t> W, A, B, C, H; size_t n_wires = 0, n_constraints = 0, n = 0; };
+
+class AlgorithmImpl;
+class Algorithm {
+  public:
+    // throws std::runtime_error with a printable message on any parse / device failure
+    Algorithm(Cipher cipher, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cfg);
+    ~Algorithm();
+    Cipher cipher() const;
+    // proves n independent statements; results[i] corresponds to reqs[i].  Thread-safe (serialised per algorithm).
+    void prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first = nullptr);
+    size_t max_batch() const;
+    std::string describe() const;    // sizes, table memory — for logs / DESIGN numbers
+    // raw timing of the last prove_batch, milliseconds per stage (solve, ntt, msm, finalize), device events
+    void last_stage_ms(float out[4]) const;
+  private:
+    std::unique_ptr<AlgorithmImpl> impl_;
+};
+
+}  // namespace gsc

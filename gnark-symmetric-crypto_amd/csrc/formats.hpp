@@ -1,0 +1,81 @@
+// Host-side decoders for the reference's binary artefacts (no field arithmetic on the host:
+// everything numeric is shipped to the GPU as raw limbs / compressed coordinates).
+//
+//  * R1CS  : gnark v0.11.0 constraint.ConstraintSystem.WriteTo layout, read by the reference at
+//            libraries/prover/impl/prove_impl.go:102-103 (format: SURVEY.md App. A).
+//  * pk    : groth16.ProvingKey.WriteTo layout, read at prove_impl.go:86-87.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+
+namespace gsc {
+
+constexpr uint32_t HINT_NBITS = 4115454955u;      // std/math/bits.nBits
+constexpr uint32_t HINT_COUNT = 2138922168u;      // std/internal/logderivarg.countHint
+constexpr uint32_t HINT_RANDOMIZE = 1774611027u;  // internal/hints.Randomize
+constexpr uint32_t HINT_BSB22 = 4156202267u;      // frontend/cs.Bsb22CommitmentComputePlaceholder
+constexpr uint32_t WIRE_CONST = 0xFFFFFFFFu;
+
+enum BlueprintKind { BP_HINT = 0, BP_R1C = 1, BP_LOOKUP = 2 };
+
+struct R1csFile {
+    size_t n_public = 0, n_secret = 0, n_internal = 0, n_constraints = 0;
+    size_t n_wires() const { return n_public + n_secret + n_internal; }
+    std::vector<uint32_t> calldata;
+    std::vector<size_t> instr_start;                 // n_instr + 1
+    std::vector<uint32_t> blueprint, constraint_off, wire_off;
+    std::vector<std::vector<uint32_t>> levels;
+    std::vector<BlueprintKind> bp_kind;
+    std::vector<std::vector<uint32_t>> bp_entries;   // lookup blueprints: EntriesCalldata
+    std::vector<uint32_t> coeff_limbs;               // n_coeff * 8 u32 limbs, little-endian, Montgomery (as stored)
+    size_t n_coeff() const { return coeff_limbs.size() / 8; }
+    bool has_commitment = false;
+    uint32_t commit_wire = 0;
+    std::vector<uint32_t> commit_private;
+    size_t n_public_committed = 0;
+    size_t n_instr() const { return blueprint.size(); }
+};
+// throws std::runtime_error on malformed input
+R1csFile parse_r1cs(const uint8_t* buf, size_t len);
+
+// One compressed point as stored in the key file, split into (x bytes big-endian with the flag bits
+// cleared, flag).  flag: 0x80 smaller y, 0xC0 larger y, 0x40 infinity.
+struct PkFile {
+    uint64_t domain_n = 0;
+    uint8_t n_inv[32], omega[32], omega_inv[32], coset_g[32], coset_g_inv[32];   // Fr, big-endian canonical
+    // G1 points: 32 bytes each (flag still in the top bits of byte 0)
+    std::vector<uint8_t> g1_alpha, g1_beta, g1_delta, g1_A, g1_B, g1_Z, g1_K;
+    // G2 points: 64 bytes each (X.A1 | X.A0)
+    std::vector<uint8_t> g2_beta, g2_delta, g2_B;
+    uint64_t n_wires = 0;
+    std::vector<uint8_t> inf_A, inf_B;
+    bool has_commitment_key = false;
+    std::vector<uint8_t> ped_basis, ped_basis_sigma;   // G1, 32 bytes each
+};
+PkFile parse_pk(const uint8_t* buf, size_t len);
+
+// ---- device solver program (built once per algorithm from the R1CS instruction list) ----
+// Word stream; every op starts with a header word: opcode | (total_words << 8).
+enum SolverOp : uint32_t {
+    OP_END = 0,
+    OP_R1C = 1,       // [hdr, loc, nL, nR, nO, constraint, unk_wire, unk_coeff, terms(cid,wid)...]   loc 0 none,1 L,2 R,3 O
+    OP_NBITS = 2,     // [hdr, out0, nOut, nTerms, terms...]
+    OP_COUNT = 3,     // [hdr, out0, nOut(=nTable), nVars, nQueries, then (nTable+nQueries)*nVars linear expressions: n, terms...]
+    OP_LOOKUP = 4,    // [hdr, out0, nIn, table_id, then nIn linear expressions]
+    OP_RANDOMIZE = 5, // [hdr, out0, nOut]
+    OP_COMMIT = 6,    // [hdr, out0, nOut]   value supplied by the host (commitment challenge) per proof
+};
+struct SolverProgram {
+    std::vector<uint32_t> words;
+    // lookup tables flattened: table t entry e -> coefficient id (entries are constant expressions)
+    std::vector<uint32_t> lookup_coeff;      // n_tables * 256
+    size_t n_tables = 0;
+    // index of the OP_COMMIT op's word offset (program is split there when a commitment exists): [0,split) then [split,end)
+    size_t split_word = 0;
+    size_t n_ops = 0, n_inversions = 0;
+};
+SolverProgram build_solver_program(const R1csFile& cs);
+
+}  // namespace gsc

@@ -1,0 +1,215 @@
+// InitAlgorithm-time kernels: point decompression, fixed-base digit tables, NTT constants.
+//
+// Replaces, on the GPU, the work hidden in groth16.ProvingKey.ReadFrom
+// (reference libraries/prover/impl/prove_impl.go:86-87): ~10^5 Fp square roots to
+// decompress the key, plus what gnark precomputes in its fft.Domain.  The digit tables are new: they trade
+// the 288 GB of HBM for the bucket pass of Pippenger.
+#include "kernels.hpp"
+
+namespace gsc {
+using namespace bn254;
+
+namespace {
+
+__device__ __forceinline__ fe fe_from_be_bytes(const uint8_t* b, bool clear_flags) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t* q = b + 28 - 4 * i;
+        uint32_t b0 = q[0];
+        if (clear_flags && i == 7) b0 &= 0x3F;
+        r.l[i] = (b0 << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    }
+    return r;
+}
+__device__ __forceinline__ bool fe_lt_mod_p(const fe& a) {
+    for (int i = 7; i >= 0; i--) { if (a.l[i] < FpParams::mod(i)) return true; if (a.l[i] > FpParams::mod(i)) return false; }
+    return false;
+}
+// (p+1)/4 — p = 3 mod 4, so a^((p+1)/4) is a square root of a when one exists
+__device__ __noinline__ fe fp_sqrt_candidate(const fe& a) {
+    const uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
+    return Fp::pow(a, e);
+}
+
+__global__ void k_decompress_g1(const uint8_t* in, G1Aff* out, uint8_t* status, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* b = in + 32 * i;
+    uint8_t flag = b[0] & 0xC0;
+    G1Aff r; uint8_t st = 0;
+    if (flag == 0x40) { r.x = Fp::from_u32(1); r.y = Fp::from_u32(2); st = 2; }
+    else {
+        fe xc = fe_from_be_bytes(b, true);
+        if (!fe_lt_mod_p(xc) || flag == 0) st = 1;
+        fe x = Fp::to_mont(xc);
+        fe rhs = Fp::add(Fp::mul(Fp::sqr(x), x), Fp::from_u32(3));
+        fe y = fp_sqrt_candidate(rhs);
+        if (!Fp::eq(Fp::sqr(y), rhs)) st = 1;
+        bool large = Fp::lex_large(y);
+        if ((flag == 0xC0) != large) y = Fp::neg(y);
+        r.x = x; r.y = y;
+    }
+    out[i] = r; status[i] = st;
+}
+
+// Fp2 square root by the norm method: a = (x0 + x1 u)^2 => x0^2 = (a0 +- sqrt(a0^2 + a1^2)) / 2, x1 = a1 / (2 x0)
+__device__ __noinline__ bool fp2_sqrt(const fe2& a, fe2& out) {
+    fe2 x;
+    if (Fp::is_zero(a.a1)) {
+        fe s = fp_sqrt_candidate(a.a0);
+        if (Fp::eq(Fp::sqr(s), a.a0)) { x.a0 = s; x.a1 = Fp::zero(); }
+        else { fe na = Fp::neg(a.a0); s = fp_sqrt_candidate(na); if (!Fp::eq(Fp::sqr(s), na)) return false; x.a0 = Fp::zero(); x.a1 = s; }
+    } else {
+        fe nrm = Fp::add(Fp::sqr(a.a0), Fp::sqr(a.a1));
+        fe s = fp_sqrt_candidate(nrm);
+        if (!Fp::eq(Fp::sqr(s), nrm)) return false;
+        fe half = Fp::inv(Fp::from_u32(2));
+        fe t = Fp::mul(Fp::add(a.a0, s), half);
+        fe x0 = fp_sqrt_candidate(t);
+        if (!Fp::eq(Fp::sqr(x0), t)) {
+            t = Fp::mul(Fp::sub(a.a0, s), half);
+            x0 = fp_sqrt_candidate(t);
+            if (!Fp::eq(Fp::sqr(x0), t)) return false;
+        }
+        x.a0 = x0; x.a1 = Fp::mul(a.a1, Fp::inv(Fp::dbl(x0)));
+    }
+    if (!Fp2::eq(Fp2::sqr(x), a)) return false;
+    out = x; return true;
+}
+
+__global__ void k_decompress_g2(const uint8_t* in, G2Aff* out, uint8_t* status, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* b = in + 64 * i;
+    uint8_t flag = b[0] & 0xC0;
+    G2Aff r; uint8_t st = 0;
+    // twist coefficient b' = 3/(9+u) = 3*(9-u)/82
+    fe inv82 = Fp::inv(Fp::from_u32(82));
+    fe2 bt; bt.a0 = Fp::mul(Fp::from_u32(27), inv82); bt.a1 = Fp::neg(Fp::mul(Fp::from_u32(3), inv82));
+    if (flag == 0x40) {
+        // any finite point will do for a base that is never selected: use x = 0 is not on the twist in general, so
+        // derive one deterministically: try x = (k, 0) for k = 1, 2, ... until x^3 + b' is a square.
+        st = 2;
+        for (uint32_t k = 1; k < 64; k++) {
+            fe2 x; x.a0 = Fp::from_u32(k); x.a1 = Fp::zero();
+            fe2 rhs = Fp2::add(Fp2::mul(Fp2::sqr(x), x), bt), y;
+            if (fp2_sqrt(rhs, y)) { r.x = x; r.y = y; break; }
+        }
+    } else {
+        fe x1c = fe_from_be_bytes(b, true), x0c = fe_from_be_bytes(b + 32, false);
+        if (!fe_lt_mod_p(x1c) || !fe_lt_mod_p(x0c) || flag == 0) st = 1;
+        fe2 x; x.a0 = Fp::to_mont(x0c); x.a1 = Fp::to_mont(x1c);
+        fe2 rhs = Fp2::add(Fp2::mul(Fp2::sqr(x), x), bt), y;
+        if (!fp2_sqrt(rhs, y)) { st = 1; y = Fp2::zero(); }
+        bool large = Fp2::lex_large(y);
+        if ((flag == 0xC0) != large) y = Fp2::neg(y);
+        r.x = x; r.y = y;
+    }
+    out[i] = r; status[i] = st;
+}
+
+__global__ void k_fr_from_be(const uint8_t* in, fe* out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = Fr::to_mont(fe_from_be_bytes(in + 32 * i, false));
+}
+__global__ void k_fr_inverse(const fe* in, fe* out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = Fr::inv(in[i]);
+}
+
+// One thread per table row (base k, window j).  Forward pass: E_d = d*Bj in XYZZ with the running product of the
+// ZZZ_d parked in the row's own slots; one inversion per row; the backward pass walks E_d = E_{d+1} - Bj and
+// writes the affine entries (Montgomery batch inversion without any scratch buffer).
+template <class F>
+__global__ void k_build_table(const Aff<F>* bases, size_t nbases, int c, int nwin, Aff<F>* table) {
+    using C = Curve<F>;
+    using E = typename F::E;
+    size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= nbases * (size_t)nwin) return;
+    size_t k = row / nwin; int j = (int)(row % nwin);
+    const size_t D = (size_t)1 << (c - 1);
+    Xyzz<F> P = C::from_aff(bases[k]);
+    for (int t = 0; t < c * j; t++) P = C::dbl(P);
+    Aff<F> Bj = C::to_aff(P);
+    Aff<F>* out = table + row * D;
+    Xyzz<F> Ed = C::from_aff(Bj);
+    E prefix = F::one();
+    for (size_t d = 1; d <= D; d++) {
+        if (d > 1) Ed = C::madd(Ed, Bj);
+        out[d - 1].x = prefix;                 // product of ZZZ_1 .. ZZZ_{d-1}
+        prefix = F::mul(prefix, Ed.zzz);
+    }
+    E inv = F::inv(prefix);
+    Aff<F> nBj = C::neg(Bj);
+    for (size_t d = D; d >= 1; d--) {
+        E pre = out[d - 1].x;
+        E izzz = F::mul(inv, pre);             // 1 / ZZZ_d
+        inv = F::mul(inv, Ed.zzz);
+        E izz = F::mul(F::sqr(Ed.zz), F::sqr(izzz));   // 1/ZZ = ZZ^2 / ZZZ^2
+        Aff<F> a; a.x = F::mul(Ed.x, izz); a.y = F::mul(Ed.y, izzz);
+        out[d - 1] = a;
+        if (d > 1) Ed = C::madd(Ed, nBj);
+    }
+}
+
+__device__ __forceinline__ fe fr_pow_u32(const fe& a, uint32_t e) {
+    fe acc = Fr::one(); bool started = false;
+    for (int i = 31; i >= 0; i--) {
+        if (started) acc = Fr::sqr(acc);
+        if ((e >> i) & 1) { acc = started ? Fr::mul(acc, a) : a; started = true; }
+    }
+    return acc;
+}
+__global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
+                                fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = 1u << L;
+    if (i >= n) return;
+    if (i < n / 2) { tw_fwd[i] = fr_pow_u32(*omega, i); tw_inv[i] = fr_pow_u32(*omega_inv, i); }
+    uint32_t br = __brev(i) >> (32 - L);
+    scale_mid[i] = Fr::mul(*n_inv, fr_pow_u32(*g, br));
+    scale_out[i] = Fr::from_mont(Fr::mul(*n_inv, fr_pow_u32(*g_inv, br)));
+    if (i == 0) {
+        fe gn = *g;
+        for (int t = 0; t < L; t++) gn = Fr::sqr(gn);
+        *den_inv = Fr::inv(Fr::sub(gn, Fr::one()));
+    }
+}
+
+}  // namespace
+
+static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+void launch_decompress_g1(const uint8_t* in, G1Aff* out, uint8_t* status, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_decompress_g1, dim3(blocks_for(n, 64)), dim3(64), 0, s, in, out, status, n);
+}
+void launch_decompress_g2(const uint8_t* in, G2Aff* out, uint8_t* status, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_decompress_g2, dim3(blocks_for(n, 64)), dim3(64), 0, s, in, out, status, n);
+}
+void launch_fr_from_be(const uint8_t* in, fe* out, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_fr_from_be, dim3(blocks_for(n, 64)), dim3(64), 0, s, in, out, n);
+}
+void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_fr_inverse, dim3(blocks_for(n, 64)), dim3(64), 0, s, in, out, n);
+}
+void launch_build_table_g1(const G1Aff* bases, size_t nbases, int c, int nwin, G1Aff* table, hipStream_t s) {
+    size_t rows = nbases * (size_t)nwin;
+    if (rows) hipLaunchKernelGGL(k_build_table<Fp>, dim3(blocks_for(rows, 64)), dim3(64), 0, s,
+                                 reinterpret_cast<const Aff<Fp>*>(bases), nbases, c, nwin, reinterpret_cast<Aff<Fp>*>(table));
+}
+void launch_build_table_g2(const G2Aff* bases, size_t nbases, int c, int nwin, G2Aff* table, hipStream_t s) {
+    size_t rows = nbases * (size_t)nwin;
+    if (rows) hipLaunchKernelGGL(k_build_table<Fp2>, dim3(blocks_for(rows, 64)), dim3(64), 0, s,
+                                 reinterpret_cast<const Aff<Fp2>*>(bases), nbases, c, nwin, reinterpret_cast<Aff<Fp2>*>(table));
+}
+void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
+                          fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s) {
+    size_t n = (size_t)1 << L;
+    hipLaunchKernelGGL(k_ntt_constants, dim3(blocks_for(n, 64)), dim3(64), 0, s, omega, omega_inv, g, g_inv, n_inv, L,
+                       tw_fwd, tw_inv, scale_mid, scale_out, den_inv);
+}
+
+}  // namespace gsc

@@ -1,0 +1,200 @@
+// Fixed-base multi-scalar multiplication over HBM-resident digit tables, and proof assembly.
+//
+// Replaces the five MultiExp calls of groth16.Prove (reference libraries/prover/impl/provers.go:148,216;
+// gnark-crypto (*G1Jac).MultiExp / (*G2Jac).MultiExp — SURVEY.md §8(a) a8-a12, algebra App. D).
+//
+// Every base of a proving key is fixed for the life of the process, and an MI355X has 288 GB of HBM, so
+// InitAlgorithm precomputes T[k][j][d] = d * 2^(c j) * P_k for all signed c-bit digits d (k_init.hip).
+// An MSM is then a pure gather-accumulate: sum_k sum_j +-T[k][j][|d_kj|] — no buckets, no sorting, no
+// atomics, no inter-thread hazards.  Lanes of a wave are 64 proofs working on the same base k, so the
+// scalar loads are coalesced (2 KiB per wave) and the table gathers of a wave fall into one 2^(c-1)*64 B row.
+// Partial sums per (slice of bases, proof) are reduced with wavefront __shfl_xor butterflies.
+#include "kernels.hpp"
+
+namespace gsc {
+using namespace bn254;
+
+namespace {
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <class F> struct AffLoader;
+template <> struct AffLoader<Fp> {
+    __device__ __forceinline__ static Aff<Fp> load(const void* table, size_t idx) {
+        const fe* q = reinterpret_cast<const fe*>(table) + 2 * idx;
+        return Aff<Fp>{load_fe(q), load_fe(q + 1)};
+    }
+};
+template <> struct AffLoader<Fp2> {
+    __device__ __forceinline__ static Aff<Fp2> load(const void* table, size_t idx) {
+        const fe* q = reinterpret_cast<const fe*>(table) + 4 * idx;
+        Aff<Fp2> a; a.x.a0 = load_fe(q); a.x.a1 = load_fe(q + 1); a.y.a0 = load_fe(q + 2); a.y.a1 = load_fe(q + 3);
+        return a;
+    }
+};
+
+// |s| <= (r-1)/2 after sign normalisation; returns true when the point must be negated
+__device__ __forceinline__ bool sign_normalise(fe& s) {
+    // (r-1)/2
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        const uint32_t lo = FrParams::mod(i) - (i == 0 ? 1u : 0u);
+        const uint32_t hi = i < 7 ? FrParams::mod(i + 1) : 0u;
+        const uint32_t h = (lo >> 1) | (hi << 31);
+        if (!decided && s.l[i] != h) { gt = s.l[i] > h; decided = true; }
+    }
+    if (gt) {
+        uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)FrParams::mod(i) - s.l[i] - br; s.l[i] = (uint32_t)d; br = (d >> 32) & 1; }
+    }
+    return gt;
+}
+
+__device__ __forceinline__ uint32_t bits_at(const fe& s, uint32_t pos, uint32_t c) {
+    if (pos >= 256) return 0;
+    const uint32_t w = pos >> 5, sh = pos & 31;
+    uint64_t v = s.l[w];
+    if (w + 1 < 8) v |= (uint64_t)s.l[w + 1] << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1);
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void k_msm(MsmArgs a) {
+    using C = Curve<F>;
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t slice = blockIdx.y;
+    const size_t per = (a.nbases + a.nslices - 1) / a.nslices;
+    const size_t k0 = slice * per, k1 = k0 + per < a.nbases ? k0 + per : a.nbases;
+    const uint32_t c = a.c, nwin = a.nwin, D = 1u << (c - 1);
+    Xyzz<F> acc = C::inf();
+    for (size_t k = k0; k < k1; k++) {
+        const size_t row = a.rows ? uni(a.rows[k]) : k;
+        fe s = load_fe(a.scalars + row * a.batch + p);
+        if (a.scalars_mont) s = Fr::from_mont(s);
+        const bool neg = sign_normalise(s);
+        // number of windows this lane needs: highest set bit / c + 1 (+1 for a possible carry)
+        int top = -1;
+#pragma unroll
+        for (int i = 7; i >= 0; i--) if (top < 0 && s.l[i]) top = 32 * i + 31 - __clz(s.l[i]);
+        uint32_t need = top < 0 ? 0u : (uint32_t)top / c + 2u;
+        if (need > nwin) need = nwin;
+        uint32_t carry = 0;
+        for (uint32_t j = 0; j < need; j++) {
+            uint32_t raw = bits_at(s, j * c, c) + carry;
+            bool dneg = false;
+            if (raw > D) { raw = (1u << c) - raw; dneg = true; carry = 1; } else carry = 0;
+            if (raw) {
+                Aff<F> e = AffLoader<F>::load(a.table, ((size_t)k * nwin + j) * D + (raw - 1));
+                if (dneg != neg) e.y = F::neg(e.y);
+                acc = C::madd(acc, e);
+            }
+        }
+    }
+    Xyzz<F>* out = reinterpret_cast<Xyzz<F>*>(a.partial);
+    out[slice * a.batch + p] = acc;
+}
+
+__device__ __forceinline__ fe shfl_xor_fe(const fe& v, int m) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__shfl_xor((int)v.l[i], m);
+    return r;
+}
+__device__ __forceinline__ fe2 shfl_xor_fe(const fe2& v, int m) { return fe2{shfl_xor_fe(v.a0, m), shfl_xor_fe(v.a1, m)}; }
+
+// one wave sums up to 64 slices of one proof: lanes = slices, butterfly over __shfl_xor
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_reduce(const Xyzz<F>* partial, size_t nslices, size_t batch, Xyzz<F>* out) {
+    using C = Curve<F>;
+    const size_t p = blockIdx.x, grp = blockIdx.y;
+    const size_t slice = grp * 64 + threadIdx.x;
+    Xyzz<F> v = slice < nslices ? partial[slice * batch + p] : C::inf();
+    for (int m = 32; m >= 1; m >>= 1) {
+        Xyzz<F> o;
+        o.x = shfl_xor_fe(v.x, m); o.y = shfl_xor_fe(v.y, m); o.zz = shfl_xor_fe(v.zz, m); o.zzz = shfl_xor_fe(v.zzz, m);
+        v = C::add(v, o);
+    }
+    if (threadIdx.x == 0) out[grp * batch + p] = v;
+}
+
+// ---- proof assembly ----
+__device__ __forceinline__ void store_canon(uint8_t* dst, const fe& mont) {
+    fe c = Fp::from_mont(mont);
+    uint32_t* q = reinterpret_cast<uint32_t*>(dst);
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = c.l[i];
+}
+
+// role 0: Ar = sumA, t0 = s * Ar.  role 1: Bs1 = sumB1, t1 = r * Bs1.   tmp[role][proof]
+__global__ __launch_bounds__(64) void k_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch,
+                                                       G1Xyzz* tmp, uint8_t* out, uint8_t* flags) {
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const int role = blockIdx.y;
+    if (p >= batch) return;
+    const Xyzz<Fp>* src = reinterpret_cast<const Xyzz<Fp>*>(role == 0 ? sumA : sumB1) + p;
+    Xyzz<Fp> P = *src;
+    const uint32_t* sc = reinterpret_cast<const uint32_t*>(rs + 64 * p) + (role == 0 ? 8 : 0);   // role 0 uses s, role 1 uses r
+    Xyzz<Fp> acc = G1::inf();
+    if (!G1::is_inf(P)) {
+        Aff<Fp> A = G1::to_aff(P);
+        if (role == 0) { store_canon(out + 256 * p, A.x); store_canon(out + 256 * p + 32, A.y); }
+        for (int i = 253; i >= 0; i--) {
+            acc = G1::dbl(acc);
+            if ((sc[i >> 5] >> (i & 31)) & 1u) acc = G1::madd(acc, A);
+        }
+    } else if (role == 0) {
+        atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), 1u << (8 * (p & 3)));
+    }
+    reinterpret_cast<Xyzz<Fp>*>(tmp)[(size_t)role * batch + p] = acc;
+}
+__global__ __launch_bounds__(64) void k_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp,
+                                                     size_t batch, uint8_t* out, uint8_t* flags) {
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= batch) return;
+    const int role = blockIdx.y;
+    uint32_t fl = 0;
+    if (role == 0) {
+        const Xyzz<Fp>* K = reinterpret_cast<const Xyzz<Fp>*>(sumK);
+        const Xyzz<Fp>* Z = reinterpret_cast<const Xyzz<Fp>*>(sumZ);
+        const Xyzz<Fp>* T = reinterpret_cast<const Xyzz<Fp>*>(tmp);
+        Xyzz<Fp> v = G1::add(G1::add(K[p], Z[p]), G1::add(T[p], T[batch + p]));
+        if (G1::is_inf(v)) fl |= 4;
+        else { Aff<Fp> A = G1::to_aff(v); store_canon(out + 256 * p + 192, A.x); store_canon(out + 256 * p + 224, A.y); }
+    } else {
+        Xyzz<Fp2> v = reinterpret_cast<const Xyzz<Fp2>*>(sumB2)[p];
+        if (G2::is_inf(v)) fl |= 2;
+        else {
+            Aff<Fp2> A = G2::to_aff(v);
+            store_canon(out + 256 * p + 64, A.x.a0); store_canon(out + 256 * p + 96, A.x.a1);
+            store_canon(out + 256 * p + 128, A.y.a0); store_canon(out + 256 * p + 160, A.y.a1);
+        }
+    }
+    if (fl) atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), fl << (8 * (p & 3)));
+}
+
+}  // namespace
+
+void launch_msm_g1(const MsmArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_msm<Fp>, dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
+}
+void launch_msm_g2(const MsmArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_msm<Fp2>, dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
+}
+void launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_msm_reduce<Fp>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
+                       reinterpret_cast<const Xyzz<Fp>*>(partial), nslices, batch, reinterpret_cast<Xyzz<Fp>*>(out));
+}
+void launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_msm_reduce<Fp2>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
+                       reinterpret_cast<const Xyzz<Fp2>*>(partial), nslices, batch, reinterpret_cast<Xyzz<Fp2>*>(out));
+}
+void launch_finalize(const G1Xyzz* sumA, const G1Xyzz* sumB1, const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ,
+                     const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
+    const unsigned nb = (unsigned)((batch + 63) / 64);
+    hipLaunchKernelGGL(k_fin_scalarmul, dim3(nb, 2), dim3(64), 0, s, sumA, sumB1, rs, batch, tmp, out, flags);
+    hipLaunchKernelGGL(k_fin_combine, dim3(nb, 2), dim3(64), 0, s, sumB2, sumK, sumZ, tmp, batch, out, flags);
+}
+
+}  // namespace gsc

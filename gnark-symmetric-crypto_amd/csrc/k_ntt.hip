@@ -1,0 +1,212 @@
+// Quotient polynomial H = (A*B - C) / (X^n - 1) over BN254 Fr, batched over proofs.
+//
+// Replaces computeH inside groth16.Prove (reference libraries/prover/impl/provers.go:148,216; gnark
+// backend/groth16/bn254.computeH + gnark-crypto fr/fft — SURVEY.md §8(a) a7, mathematics App. D):
+//   3 inverse NTTs (DIF, natural -> bit-reversed), coset scaling, 3 forward NTTs (DIT, bit-reversed -> natural),
+//   pointwise (a*b - c)/(g^n - 1), 1 inverse coset NTT (DIF) whose bit-reversed output order is exactly the
+//   order pk.G1.Z is stored in.
+//
+// Data stay in the solver's [index][proof] layout for the whole pipeline (no transposes).  n = 2^L is split
+// as 2^Lhi x 2^Llo: "strided" kernels own the stages that couple the top Lhi index bits (groups of 2^Lhi
+// elements at stride 2^Llo), "contiguous" kernels the low Llo bits.  Because DIF ends where DIT begins, the
+// seven transforms take four kernels:
+//   K1 strided DIF head (a,b,c) | K2 contiguous DIF tail + coset scale + DIT head (a,b,c)
+//   K3 strided DIT tail (a,b,c) + pointwise + strided DIF head (h) | K4 contiguous DIF tail + final scale (h).
+// Every kernel stages a tile of P proofs x 2^Lhi (or 2^Llo) elements in LDS, limb-major, one radix-2 stage
+// per barrier; global accesses are P*32 = 128-byte segments.
+#include "kernels.hpp"
+
+namespace gsc {
+using namespace bn254;
+
+namespace {
+
+constexpr int P = 4;   // proofs per workgroup tile
+
+struct Tile {
+    uint32_t* lds; uint32_t plane;   // plane = elements * P (words per limb plane)
+    __device__ __forceinline__ fe get(uint32_t e, uint32_t q) const {
+        fe r; const uint32_t o = e * P + q;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = lds[i * plane + o];
+        return r;
+    }
+    __device__ __forceinline__ void put(uint32_t e, uint32_t q, const fe& v) const {
+        const uint32_t o = e * P + q;
+#pragma unroll
+        for (int i = 0; i < 8; i++) lds[i * plane + o] = v.l[i];
+    }
+};
+
+// one DIF stage on the tile: pairs (e1, e1 + he); twiddle exponent = (gidx(e1) mod hg) << s
+template <bool STRIDED>
+__device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, uint32_t hg, int s, int Llo, uint32_t tile_id, const fe* tw) {
+    const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
+    const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
+    const uint32_t ex = (gi & (hg - 1)) << s;
+    fe u = t.get(e1, q), v = t.get(e2, q);
+    fe sum = Fr::add(u, v), dif = Fr::sub(u, v);
+    if (ex) dif = Fr::mul(dif, load_fe(tw + ex));
+    t.put(e1, q, sum); t.put(e2, q, dif);
+}
+// one DIT stage: half = 2^s; twiddle exponent = (gidx(e1) mod 2^s) << (L-1-s)
+template <bool STRIDED>
+__device__ __forceinline__ void dit_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, int s, int L, int Llo, uint32_t tile_id, const fe* tw) {
+    const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
+    const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
+    const uint32_t ex = (gi & ((1u << s) - 1)) << (L - 1 - s);
+    fe u = t.get(e1, q), v = t.get(e2, q);
+    if (ex) v = Fr::mul(v, load_fe(tw + ex));
+    t.put(e1, q, Fr::add(u, v)); t.put(e2, q, Fr::sub(u, v));
+}
+
+// K1: strided DIF head.  grid (2^Llo, batch/P, nvec); block (2^(Lhi-1) * P)
+__global__ void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, size_t batch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
+    const uint32_t G = 1u << Lhi;
+    fe* vec = blockIdx.z == 0 ? v0 : blockIdx.z == 1 ? v1 : v2;
+    const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
+    const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
+    Tile t{smem, G * P};
+    for (uint32_t e = bf; e < G; e += G / 2) {
+        const size_t idx = ((size_t)e << Llo) + g;
+        fe x = idx < m ? load_fe(vec + idx * batch + q0 + q) : Fr::zero();
+        t.put(e, q, x);
+    }
+    __syncthreads();
+    for (int s = 0; s < Lhi; s++) {
+        const uint32_t hg = 1u << (L - 1 - s);
+        dif_stage<true>(t, bf, q, hg >> Llo, hg, s, Llo, g, pl.tw_inv);
+        __syncthreads();
+    }
+    for (uint32_t e = bf; e < G; e += G / 2) {
+        const size_t idx = ((size_t)e << Llo) + g;
+        store_fe(vec + idx * batch + q0 + q, t.get(e, q));
+    }
+}
+
+// K2: contiguous DIF tail, coset scale, contiguous DIT head.  grid (2^Lhi, batch/P, nvec); block (2^(Llo-1) * P)
+__global__ void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
+    const uint32_t Cn = 1u << Llo;
+    fe* vec = blockIdx.z == 0 ? v0 : blockIdx.z == 1 ? v1 : v2;
+    const uint32_t b = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
+    const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
+    Tile t{smem, Cn * P};
+    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+        const size_t idx = ((size_t)b << Llo) + e;
+        t.put(e, q, load_fe(vec + idx * batch + q0 + q));
+    }
+    __syncthreads();
+    for (int s = Lhi; s < L; s++) {
+        const uint32_t hg = 1u << (L - 1 - s);
+        dif_stage<false>(t, bf, q, hg, hg, s, Llo, b, pl.tw_inv);
+        __syncthreads();
+    }
+    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+        const size_t idx = ((size_t)b << Llo) + e;
+        t.put(e, q, Fr::mul(t.get(e, q), load_fe(pl.scale_mid + idx)));
+    }
+    __syncthreads();
+    for (int s = 0; s < Llo; s++) {
+        dit_stage<false>(t, bf, q, 1u << s, s, L, Llo, b, pl.tw_fwd);
+        __syncthreads();
+    }
+    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+        const size_t idx = ((size_t)b << Llo) + e;
+        store_fe(vec + idx * batch + q0 + q, t.get(e, q));
+    }
+}
+
+// K3: strided DIT tail for a, b, c; h = (a*b - c) * den_inv; strided DIF head for h (written over a).
+__global__ void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const fe* vc, size_t batch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
+    const uint32_t G = 1u << Lhi;
+    const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
+    const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
+    Tile t{smem, G * P};
+    fe r1[3], r2[3];
+    for (int k = 0; k < 3; k++) {
+        const fe* vec = k == 0 ? va : k == 1 ? vb : vc;
+        for (uint32_t e = bf; e < G; e += G / 2) {
+            const size_t idx = ((size_t)e << Llo) + g;
+            t.put(e, q, load_fe(vec + idx * batch + q0 + q));
+        }
+        __syncthreads();
+        for (int s = Llo; s < L - 1; s++) {
+            dit_stage<true>(t, bf, q, 1u << (s - Llo), s, L, Llo, g, pl.tw_fwd);
+            __syncthreads();
+        }
+        {   // last DIT stage (s = L-1): pairs (bf, bf + G/2), results stay in registers
+            const uint32_t e1 = bf, e2 = bf + G / 2;
+            const uint32_t gi = (e1 << Llo) + g;
+            const uint32_t ex = gi & ((1u << (L - 1)) - 1);
+            fe u = t.get(e1, q), v = t.get(e2, q);
+            if (ex) v = Fr::mul(v, load_fe(pl.tw_fwd + ex));
+            r1[k] = Fr::add(u, v); r2[k] = Fr::sub(u, v);
+        }
+        __syncthreads();
+    }
+    const fe den = load_fe(pl.den_inv);
+    fe h1 = Fr::mul(Fr::sub(Fr::mul(r1[0], r1[1]), r1[2]), den);
+    fe h2 = Fr::mul(Fr::sub(Fr::mul(r2[0], r2[1]), r2[2]), den);
+    {   // first DIF stage (s = 0): same pairs; twiddle exponent = gidx(e1) mod n/2
+        const uint32_t e1 = bf, e2 = bf + G / 2;
+        const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
+        fe sum = Fr::add(h1, h2), dif = Fr::sub(h1, h2);
+        if (ex) dif = Fr::mul(dif, load_fe(pl.tw_inv + ex));
+        t.put(e1, q, sum); t.put(e2, q, dif);
+    }
+    __syncthreads();
+    for (int s = 1; s < Lhi; s++) {
+        const uint32_t hg = 1u << (L - 1 - s);
+        dif_stage<true>(t, bf, q, hg >> Llo, hg, s, Llo, g, pl.tw_inv);
+        __syncthreads();
+    }
+    for (uint32_t e = bf; e < G; e += G / 2) {
+        const size_t idx = ((size_t)e << Llo) + g;
+        store_fe(va + idx * batch + q0 + q, t.get(e, q));
+    }
+}
+
+// K4: contiguous DIF tail on h, then scale by n^-1 g^-j and leave Montgomery form.
+__global__ void k_ntt_final_contig(NttPlan pl, fe* vh, size_t batch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
+    const uint32_t Cn = 1u << Llo;
+    const uint32_t b = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
+    const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
+    Tile t{smem, Cn * P};
+    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+        const size_t idx = ((size_t)b << Llo) + e;
+        t.put(e, q, load_fe(vh + idx * batch + q0 + q));
+    }
+    __syncthreads();
+    for (int s = Lhi; s < L; s++) {
+        const uint32_t hg = 1u << (L - 1 - s);
+        dif_stage<false>(t, bf, q, hg, hg, s, Llo, b, pl.tw_inv);
+        __syncthreads();
+    }
+    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+        const size_t idx = ((size_t)b << Llo) + e;
+        store_fe(vh + idx * batch + q0 + q, Fr::mul(t.get(e, q), load_fe(pl.scale_out + idx)));
+    }
+}
+
+}  // namespace
+
+void launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s) {
+    const int L = p.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
+    const unsigned G = 1u << Lhi, Cn = 1u << Llo;
+    const unsigned pb = (unsigned)(batch / P);
+    const size_t lds_s = (size_t)G * P * 32, lds_c = (size_t)Cn * P * 32;
+    hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, 3), dim3(G / 2 * P), lds_s, s, p, a, b, c, m, batch);
+    hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 3), dim3(Cn / 2 * P), lds_c, s, p, a, b, c, batch);
+    hipLaunchKernelGGL(k_ntt_pointwise_strided, dim3(Cn, pb, 1), dim3(G / 2 * P), lds_s, s, p, a, b, c, batch);
+    hipLaunchKernelGGL(k_ntt_final_contig, dim3(G, pb, 1), dim3(Cn / 2 * P), lds_c, s, p, a, batch);
+}
+
+}  // namespace gsc

@@ -1,0 +1,83 @@
+// Launchers for the gfx950 kernels (defined in k_*.hip).  Everything takes a stream and returns
+// immediately; no launcher allocates, synchronises or copies (hipGraph-capturable, guide §6 G9).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include "bn254_dev.hpp"
+
+namespace gsc {
+using bn254::fe;
+using bn254::fe2;
+
+struct G1Aff { fe x, y; };                 // 64 B, Montgomery
+struct G2Aff { fe2 x, y; };                // 128 B
+struct G1Xyzz { fe x, y, zz, zzz; };       // 128 B
+struct G2Xyzz { fe2 x, y, zz, zzz; };      // 256 B
+
+// ---- InitAlgorithm-time kernels (k_init.hip) ----
+// in: n x 32 B big-endian compressed X (flag bits in byte 0).  status[i] != 0 => not on curve / bad encoding.
+// Infinity encodings produce the generator and status 2 (caller maps the base to the zero scalar row).
+void launch_decompress_g1(const uint8_t* in, G1Aff* out, uint8_t* status, size_t n, hipStream_t s);
+void launch_decompress_g2(const uint8_t* in, G2Aff* out, uint8_t* status, size_t n, hipStream_t s);
+// canonical big-endian Fr -> Montgomery limbs
+void launch_fr_from_be(const uint8_t* in, fe* out, size_t n, hipStream_t s);
+void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s);
+// Fixed-base digit tables: table[(k*nwin + j)*D + (d-1)] = d * 2^(c*j) * base[k],  D = 2^(c-1), affine.
+void launch_build_table_g1(const G1Aff* bases, size_t nbases, int c, int nwin, G1Aff* table, hipStream_t s);
+void launch_build_table_g2(const G2Aff* bases, size_t nbases, int c, int nwin, G2Aff* table, hipStream_t s);
+// NTT constants for a domain of size 2^L: tw_fwd[i] = w^i, tw_inv[i] = w^-i (i < n/2, Montgomery);
+// scale_mid[pos] = n^-1 * g^bitrev(pos) (Montgomery); scale_out[pos] = n^-1 * g^-bitrev(pos) (plain, so that the
+// Montgomery product with it leaves the result in canonical form).
+void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
+                          fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s);
+
+// ---- witness generation (k_solver.hip) ----
+// inputs: batch x 176 B records {key[32], nonce[12], counter u32 LE, pt[64], ct[64]} (ChaCha) laid out per proof.
+// W layout: W[wire * batch + proof].
+void launch_assign_chacha(const uint8_t* inputs, fe* W, size_t batch, hipStream_t s);
+// AES records: {key[32] (zero padded), nonce[12], counter u32 LE, pt[64], ct[64]}; keylen 16 or 32
+void launch_assign_aes(const uint8_t* inputs, int keylen, fe* W, size_t batch, hipStream_t s);
+// rs: batch x 2 x 32 B little-endian canonical (r, s).  Fills rows nw..nw+3 of W: r, s, -r*s, 0 (Montgomery).
+void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, hipStream_t s);
+struct SolverArgs {
+    const uint32_t* prog; size_t first_word;       // start executing here, stop at OP_END or OP_COMMIT (unless resume)
+    const fe* coeff; const fe* coeff_inv; const uint32_t* lookup_coeff;
+    fe* W; fe* A; fe* B; fe* C; size_t batch;
+    uint32_t* status;                               // per proof: 0 ok, else 1 + op index of the first failing op
+    const fe* mask;                                 // per proof value for hints.Randomize (Montgomery) or nullptr
+    const fe* commit;                               // per proof commitment challenge (Montgomery) or nullptr
+    int resume;                                     // 1: first op is the OP_COMMIT to apply
+};
+void launch_solver(const SolverArgs& a, hipStream_t s);
+
+// ---- quotient polynomial (k_ntt.hip) ----
+struct NttPlan { int L; const fe* tw_fwd; const fe* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* den_inv; };
+// a,b,c: [n][batch] Montgomery, first m rows valid (rows >= m are treated as zero and need not be initialised).
+// On return `a` holds h in canonical form: a[pos] = h_{bitrev(pos)} — the order pk.G1.Z is stored in.
+void launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s);
+
+// ---- multi-scalar multiplication (k_msm.hip) ----
+// partial[slice * batch + proof] = sum over bases k in slice of scalar[rows[k]][proof] * base_k
+struct MsmArgs {
+    const void* table; int c; int nwin; size_t nbases;
+    const uint32_t* rows;          // scalar row per base (nullptr: row k)
+    const fe* scalars;             // [row][batch]
+    int scalars_mont;              // 1: Montgomery form, 0: canonical
+    size_t batch; size_t nslices;  // slices of ceil(nbases/nslices) consecutive bases
+    void* partial;                 // G1Xyzz / G2Xyzz [nslices][batch]
+};
+void launch_msm_g1(const MsmArgs& a, hipStream_t s);
+void launch_msm_g2(const MsmArgs& a, hipStream_t s);
+// out[proof] = sum_slices partial[slice][proof]
+void launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
+void launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
+// Proof assembly: inputs are the completed sums
+//   sumA = alpha + sum A + r*delta, sumB1 = beta + sum B + s*delta, sumB2 (G2), sumK = sum K - rs*delta, sumZ.
+// rs: batch x 64 B (r, s little-endian canonical).  out: batch x 256 B = Ar.x Ar.y | Bs.x.a0 Bs.x.a1 Bs.y.a0 Bs.y.a1 | Krs.x Krs.y,
+// canonical little-endian limbs; flags[proof] bit0 Ar inf, bit1 Bs inf, bit2 Krs inf (buffer zeroed by the caller,
+// 4-byte aligned, length rounded up to 4).  tmp: scratch of 2 * batch points.
+void launch_finalize(const G1Xyzz* sumA, const G1Xyzz* sumB1, const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ,
+                     const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s);
+
+}  // namespace gsc

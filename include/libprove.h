@@ -1,0 +1,74 @@
+/* libprove.h — C-ABI of the MI355X-native Groth16 prover for the gnark-symmetric-crypto circuits.
+ *
+ * Drop-in for the header cgo generates from the reference's libraries/prover/libprove.go
+ * (`go build -buildmode=c-shared`, reference README.md:83-96): same symbol names, same argument
+ * layout (GoSlice by value, GoUint8 for bool, struct Prove_return), same ownership rules.
+ * Additions that the reference does not have are grouped at the end and prefixed gsc_ / named ProveBatch.
+ */
+#ifndef GSC_LIBPROVE_H
+#define GSC_LIBPROVE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef unsigned char GoUint8;
+typedef long long GoInt;
+typedef struct { void *data; GoInt len; GoInt cap; } GoSlice;   /* passed BY VALUE */
+struct Prove_return { void *r0; /* proofRes */ GoInt r1; /* resLen */ };
+
+/* libprove.go:17-18 — no-op that forces the dynamic loader to bind the library. */
+extern void enforce_binding(void);
+
+/* libprove.go:20-23 -> impl.InitAlgorithm (prove_impl.go:65-114).
+ * algorithmID: 0 chacha20, 1 aes-128-ctr, 2 aes-256-ctr (prove_impl.go:15-25).
+ * provingKey / r1cs: the gnark v0.11.0 files written by keygen.go:341-352 (read only during the call).
+ * Returns 1 on success or if the algorithm is already initialised, 0 on unknown id / parse failure
+ * (message on stdout, as the reference prints it). */
+extern GoUint8 InitAlgorithm(GoUint8 algorithmID, GoSlice provingKey, GoSlice r1cs);
+
+/* libprove.go:25-28 — releases a buffer returned by Prove / ProveBatch (C free()). */
+extern void Free(void *pointer);
+
+/* libprove.go:30-47 -> impl.Prove (prove_impl.go:116-143).
+ * params: JSON {"cipher","key","nonce","counter","input"} (provers.go:53-59).
+ * Returns a malloc'd, NOT NUL-terminated JSON buffer and its length:
+ *   success: {"proof":{"proofJson":"<base64>"},"publicSignals":"<base64 ciphertext>"}
+ *   failure: the JSON encoding of the Go panic value (a quoted string for message panics, an object for
+ *            decode errors); never unwinds across the ABI. */
+extern struct Prove_return Prove(GoSlice params);
+
+/* ---- additions (not in the reference) ---- */
+
+/* Proves many independent statements in one device batch.  params: JSON array of Prove inputs (ciphers may be
+ * mixed).  Returns a JSON array whose i-th element is exactly what Prove would have returned for element i. */
+extern struct Prove_return ProveBatch(GoSlice params);
+
+/* Binary batch entry used by bench.py / tests (no JSON on the timed path).
+ * cipher: algorithm id.  inputs: n records of 112 bytes {key[32] (AES-128: first 16 used), nonce[12],
+ * counter u32 little-endian, input[64]}.  proofs: n x 196 bytes, proof_lens: n (0 on failure),
+ * ciphertexts: n x 64 bytes.  Returns the number of proofs produced, or -1 if the algorithm is not initialised. */
+extern long long gsc_prove_raw(GoUint8 cipher, const uint8_t *inputs, size_t n, uint8_t *proofs, uint32_t *proof_lens, uint8_t *ciphertexts);
+
+/* TEST HOOK: fixes the prover randomness (r, s, AES commitment mask; 32-byte big-endian, < Fr modulus) for every
+ * subsequent proof of this process; pass NULLs to return to the OS CSPRNG (the default).  With it fixed the proof is a
+ * deterministic function of the inputs, which is what byte-level parity with gnark is defined on. */
+extern void gsc_set_deterministic_randomness(const uint8_t *r_be32, const uint8_t *s_be32, const uint8_t *mask_be32);
+
+/* TEST HOOK: runs one proof and copies the intermediate vectors of the device pipeline for parity tests.
+ * which: 0 W (n_wires), 1 A, 2 B, 3 C (n_constraints), 4 h (domain size; element k = h_{bitrev(k)}).
+ * Elements are 32 bytes, little-endian 32-bit limbs; W/A/B/C are in Montgomery form (x*2^256 mod r), h is canonical.
+ * Call gsc_debug_prove first; gsc_debug_vector returns the element count (or -1) and copies min(cap, size) bytes. */
+extern long long gsc_debug_prove(GoSlice params);
+extern long long gsc_debug_vector(int which, uint8_t *out, size_t cap);
+
+/* Human-readable description of an initialised algorithm (sizes, table memory); returns bytes written. */
+extern size_t gsc_describe(GoUint8 algorithmID, char *out, size_t cap);
+/* Device milliseconds of the four stages (witness, quotient, msm, assembly) of the last batch of that algorithm. */
+extern int gsc_last_stage_ms(GoUint8 algorithmID, float out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

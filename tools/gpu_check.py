@@ -1,0 +1,47 @@
+"""Quick end-to-end check on a GPU box: KAT parity of every pipeline stage + a small timing run."""
+import hashlib, json, lzma, os, sys, time, base64
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gsc_loader
+g = gsc_loader.load()
+G = os.path.join(ROOT, "tests", "golden")
+pk = open(os.path.join(G, "pk.chacha20"), "rb").read()
+cs = lzma.open(os.path.join(G, "r1cs.chacha20.xz")).read()
+t = time.time()
+ok = g.init_algorithm(0, pk, cs)
+print("InitAlgorithm:", ok, "%.2fs" % (time.time() - t), flush=True)
+if not ok:
+    sys.exit(1)
+print(g.describe(0), flush=True)
+PT = "a3f7e592aeda1507a7f51b35812dfc50a263d5a6d2df625e563b02e49c08bf30d0e7483f5b13ff079532224ee8fbc31ab1899b18e453d36d9793a8355eb0dee9"
+params = {"cipher": "chacha20", "key": [2] * 32, "nonce": [3] * 12, "counter": 3, "input": list(bytes.fromhex(PT))}
+g.set_deterministic_randomness(0, 0, 0)
+t = time.time()
+d = g.debug_prove(params)
+print("debug_prove %.2fs" % (time.time() - t), g.last_stage_ms(0), flush=True)
+be = lambda vals: b"".join(v.to_bytes(32, "big") for v in vals)
+print("W   ", hashlib.sha256(be(d["W"])).hexdigest() == "1b458bca80f40f2b9f0b6c6fc1e3b3bf1ca0a386eaaf7963f3387b3e5cd3dffa")
+print("abc ", hashlib.sha256(be(d["A"]) + be(d["B"]) + be(d["C"])).hexdigest() == "aef05402d37c97ed2c6840de6c10c484b1f14b1dff03510b7404d7a913dfb3b9")
+n = len(d["h"]); L = n.bit_length() - 1
+nat = [d["h"][int(format(j, "0%db" % L)[::-1], 2)] for j in range(n)]
+print("h   ", hashlib.sha256(be(nat[: n - 1])).hexdigest() == "35037f465d7606a5dc8b86c17df1e0224f40d8e48e1543fb6e7ffdd3c23ecf9f", "h[n-1]==0:", nat[n - 1] == 0)
+res = json.loads(g.prove(params))
+proof = base64.b64decode(res["proof"]["proofJson"])
+KAT0 = "c21d45c12d5fd77bb5211e85938971448e56ce09d02af6c6b889e1edf0c1c39ca2829d5ce21612af4ef03c6a28c380d0348fd790adb3b0027200ceeac421481a24e3e0710da3d26c41df970ed0e50e6647223d1f9f904b8ed6a3288011dd97d2e8414464d817570d0feb88fb12b741c48361a2da0725bde1bd8a66415f0f6f95000000004000000000000000000000000000000000000000000000000000000000000000"
+print("proof(r=s=0)", proof.hex() == KAT0)
+if proof.hex() != KAT0:
+    print(proof.hex())
+g.set_deterministic_randomness(0x1234567, 0xabcdef0123456789abcdef, 0)
+res = json.loads(g.prove(params))
+KAT1 = "ea49984df7447a7faa42e256b4ba77b18c134f87a9f8938bcc7722f9524b81f0a81727420993af92a92d8e28650e858ff01fbded7396dd3a41033abac4d97d5c0097d13efc1142d0730950c26c4c55037bb1dc96b9e3422eae0729ef36af113fd8fa21e5ff66d3c144a6d75436c9b87866463d76e98b68310f3bce6130d699a6000000004000000000000000000000000000000000000000000000000000000000000000"
+print("proof(r,s)  ", base64.b64decode(res["proof"]["proofJson"]).hex() == KAT1)
+g.set_deterministic_randomness(None)
+# timing
+import random
+rnd = random.Random(1)
+for n in (64, 256, 1024):
+    recs = b"".join(bytes(rnd.randrange(256) for _ in range(44)) + rnd.randrange(2**32).to_bytes(4, "little") + bytes(rnd.randrange(256) for _ in range(64)) for _ in range(n))
+    t = time.time()
+    okn, proofs, lens, cts = g.prove_raw(0, recs, n)
+    dt = time.time() - t
+    print("batch %d: ok=%d %.3fs -> %.1f proofs/s" % (n, okn, dt, n / dt), g.last_stage_ms(0), flush=True)
