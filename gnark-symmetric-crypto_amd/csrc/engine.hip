@@ -196,8 +196,21 @@ class AlgorithmImpl {
         std::vector<uint32_t> rowsZ(domain_n - 1); for (size_t i = 0; i < rowsZ.size(); i++) rowsZ[i] = (uint32_t)i;
         auto dec1 = [this](const std::vector<uint8_t>& raw, G1Aff* out) { return decompress_g1(raw, out); };
         auto dec2 = [this](const std::vector<uint8_t>& raw, G2Aff* out) { return decompress_g2(raw, out); };
-        auto bld1 = [this](const G1Aff* b, size_t n, int c, int nwin, G1Aff* t) { launch_build_table_g1(b, n, c, nwin, t, stream); };
-        auto bld2 = [this](const G2Aff* b, size_t n, int c, int nwin, G2Aff* t) { launch_build_table_g2(b, n, c, nwin, t, stream); };
+        // tables are built in chunks of rows so that the projective scratch stays below ~4 GiB
+        auto bld1 = [this](const G1Aff* b, size_t n, int c, int nwin, G1Aff* t) {
+            const size_t D = (size_t)1 << (c - 1), rows = n * (size_t)nwin;
+            size_t chunk = ((size_t)4 << 30) / (D * sizeof(G1Xyzz)); if (chunk > rows) chunk = rows; if (!chunk) chunk = 1;
+            DevBuf<G1Xyzz> scratch(chunk * D);
+            for (size_t r0 = 0; r0 < rows; r0 += chunk) launch_build_table_g1(b, r0, rows - r0 < chunk ? rows - r0 : chunk, c, nwin, t, scratch.p, stream);
+            HIP_CHECK(hipStreamSynchronize(stream));
+        };
+        auto bld2 = [this](const G2Aff* b, size_t n, int c, int nwin, G2Aff* t) {
+            const size_t D = (size_t)1 << (c - 1), rows = n * (size_t)nwin;
+            size_t chunk = ((size_t)4 << 30) / (D * sizeof(G2Xyzz)); if (chunk > rows) chunk = rows; if (!chunk) chunk = 1;
+            DevBuf<G2Xyzz> scratch(chunk * D);
+            for (size_t r0 = 0; r0 < rows; r0 += chunk) launch_build_table_g2(b, r0, rows - r0 < chunk ? rows - r0 : chunk, c, nwin, t, scratch.p, stream);
+            HIP_CHECK(hipStreamSynchronize(stream));
+        };
         build_set(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, bld1);
         build_set(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, bld1);
         build_set(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, bld1);

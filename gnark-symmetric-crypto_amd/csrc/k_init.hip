@@ -120,38 +120,40 @@ __global__ void k_fr_inverse(const fe* in, fe* out, size_t n) {
     out[i] = Fr::inv(in[i]);
 }
 
-// One thread per table row (base k, window j).  Forward pass: E_d = d*Bj in XYZZ with the running product of the
-// ZZZ_d parked in the row's own slots; one inversion per row; the backward pass walks E_d = E_{d+1} - Bj and
-// writes the affine entries (Montgomery batch inversion without any scratch buffer).
+// One thread per table row (base k, window j).  Forward pass: E_d = d*Bj in XYZZ, parked in `scratch`, with the running
+// product of the ZZZ_d parked in the row's own slots; one inversion per row; the backward pass turns every E_d into
+// its affine form (Montgomery batch inversion).  Rows [row0, row0 + nrows) are processed; scratch holds nrows*D points.
 template <class F>
-__global__ void k_build_table(const Aff<F>* bases, size_t nbases, int c, int nwin, Aff<F>* table) {
+__global__ void k_build_table(const Aff<F>* bases, size_t row0, size_t nrows, int c, int nwin, Aff<F>* table, Xyzz<F>* scratch) {
     using C = Curve<F>;
     using E = typename F::E;
-    size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (row >= nbases * (size_t)nwin) return;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nrows) return;
+    size_t row = row0 + t;
     size_t k = row / nwin; int j = (int)(row % nwin);
     const size_t D = (size_t)1 << (c - 1);
     Xyzz<F> P = C::from_aff(bases[k]);
-    for (int t = 0; t < c * j; t++) P = C::dbl(P);
+    for (int q = 0; q < c * j; q++) P = C::dbl(P);
     Aff<F> Bj = C::to_aff(P);
     Aff<F>* out = table + row * D;
+    Xyzz<F>* sc = scratch + t * D;
     Xyzz<F> Ed = C::from_aff(Bj);
     E prefix = F::one();
     for (size_t d = 1; d <= D; d++) {
         if (d > 1) Ed = C::madd(Ed, Bj);
+        sc[d - 1] = Ed;
         out[d - 1].x = prefix;                 // product of ZZZ_1 .. ZZZ_{d-1}
         prefix = F::mul(prefix, Ed.zzz);
     }
     E inv = F::inv(prefix);
-    Aff<F> nBj = C::neg(Bj);
     for (size_t d = D; d >= 1; d--) {
+        Ed = sc[d - 1];
         E pre = out[d - 1].x;
         E izzz = F::mul(inv, pre);             // 1 / ZZZ_d
         inv = F::mul(inv, Ed.zzz);
         E izz = F::mul(F::sqr(Ed.zz), F::sqr(izzz));   // 1/ZZ = ZZ^2 / ZZZ^2
         Aff<F> a; a.x = F::mul(Ed.x, izz); a.y = F::mul(Ed.y, izzz);
         out[d - 1] = a;
-        if (d > 1) Ed = C::madd(Ed, nBj);
     }
 }
 
@@ -195,15 +197,13 @@ void launch_fr_from_be(const uint8_t* in, fe* out, size_t n, hipStream_t s) {
 void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fr_inverse, dim3(blocks_for(n, 64)), dim3(64), 0, s, in, out, n);
 }
-void launch_build_table_g1(const G1Aff* bases, size_t nbases, int c, int nwin, G1Aff* table, hipStream_t s) {
-    size_t rows = nbases * (size_t)nwin;
-    if (rows) hipLaunchKernelGGL(k_build_table<Fp>, dim3(blocks_for(rows, 64)), dim3(64), 0, s,
-                                 reinterpret_cast<const Aff<Fp>*>(bases), nbases, c, nwin, reinterpret_cast<Aff<Fp>*>(table));
+void launch_build_table_g1(const G1Aff* bases, size_t row0, size_t nrows, int c, int nwin, G1Aff* table, G1Xyzz* scratch, hipStream_t s) {
+    if (nrows) hipLaunchKernelGGL(k_build_table<Fp>, dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
+                                  reinterpret_cast<const Aff<Fp>*>(bases), row0, nrows, c, nwin, reinterpret_cast<Aff<Fp>*>(table), reinterpret_cast<Xyzz<Fp>*>(scratch));
 }
-void launch_build_table_g2(const G2Aff* bases, size_t nbases, int c, int nwin, G2Aff* table, hipStream_t s) {
-    size_t rows = nbases * (size_t)nwin;
-    if (rows) hipLaunchKernelGGL(k_build_table<Fp2>, dim3(blocks_for(rows, 64)), dim3(64), 0, s,
-                                 reinterpret_cast<const Aff<Fp2>*>(bases), nbases, c, nwin, reinterpret_cast<Aff<Fp2>*>(table));
+void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c, int nwin, G2Aff* table, G2Xyzz* scratch, hipStream_t s) {
+    if (nrows) hipLaunchKernelGGL(k_build_table<Fp2>, dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
+                                  reinterpret_cast<const Aff<Fp2>*>(bases), row0, nrows, c, nwin, reinterpret_cast<Aff<Fp2>*>(table), reinterpret_cast<Xyzz<Fp2>*>(scratch));
 }
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
                           fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s) {

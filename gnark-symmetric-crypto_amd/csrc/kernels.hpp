@@ -24,8 +24,9 @@ void launch_decompress_g2(const uint8_t* in, G2Aff* out, uint8_t* status, size_t
 void launch_fr_from_be(const uint8_t* in, fe* out, size_t n, hipStream_t s);
 void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s);
 // Fixed-base digit tables: table[(k*nwin + j)*D + (d-1)] = d * 2^(c*j) * base[k],  D = 2^(c-1), affine.
-void launch_build_table_g1(const G1Aff* bases, size_t nbases, int c, int nwin, G1Aff* table, hipStream_t s);
-void launch_build_table_g2(const G2Aff* bases, size_t nbases, int c, int nwin, G2Aff* table, hipStream_t s);
+// Builds table rows [row0, row0 + nrows) (row = k*nwin + j); scratch: nrows * D projective points.
+void launch_build_table_g1(const G1Aff* bases, size_t row0, size_t nrows, int c, int nwin, G1Aff* table, G1Xyzz* scratch, hipStream_t s);
+void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c, int nwin, G2Aff* table, G2Xyzz* scratch, hipStream_t s);
 // NTT constants for a domain of size 2^L: tw_fwd[i] = w^i, tw_inv[i] = w^-i (i < n/2, Montgomery);
 // scale_mid[pos] = n^-1 * g^bitrev(pos) (Montgomery); scale_out[pos] = n^-1 * g^-bitrev(pos) (plain, so that the
 // Montgomery product with it leaves the result in canonical form).

@@ -1,0 +1,146 @@
+"""CPU tests: the oracle (oracle/) against every golden vector the reference and SURVEY App. E provide.
+
+These pin the CPU restatement before it is trusted as the checker of the HIP path.
+"""
+import hashlib
+import random
+
+import pytest
+
+from conftest import KAT, golden_bytes
+
+
+def test_field_constants_match_survey_app_i(oracle):
+    import ctypes as C
+    buf = C.create_string_buffer(32)
+    want = ["0e0a77c19a07df2f666ea36f7879462c0a78eb28f5c70b3dd35d438dc58f0d9d", "06d89f71cab8351f47ab1eff0a417ff6b5e71911d44501fbf32cfc5b538afa89",
+            "0e0a77c19a07df2f666ea36f7879462e36fc76959f60cd29ac96341c4ffffffb", "0216d0b17f4e44a58c49833d53bb808553fe3ab1e35c59e31bb8e645ae216da7"]
+    for i, w in enumerate(want):
+        oracle.lib().orc_field_const(i, buf)
+        assert buf.raw.hex() == w
+
+
+def test_pairing_is_bilinear_and_nondegenerate(oracle):
+    assert oracle.lib().orc_pairing_selftest() == 0
+
+
+def test_chacha20_rfc7539_block_vector(oracle):
+    # RFC 7539 section 2.3.2 — the same vector the reference checks in circuits/chachaV3/chacha_test.go:95-105
+    import ctypes as C
+    key = bytes(range(32)); nonce = bytes.fromhex("000000090000004a00000000")
+    out = C.create_string_buffer(64)
+    oracle.lib().orc_chacha20_block(key, nonce, 1, out)
+    assert out.raw.hex() == ("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                             "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+
+
+def test_chacha20_matches_reference_public_signals(oracle):
+    # README.md:48 publicSignals == ChaCha20(key=2x32, nonce=3x12, ctr=3) xor core_test.go:285 input
+    assert oracle.chacha20_xor(KAT["key"], KAT["nonce"], KAT["counter"], KAT["input"]) == KAT["ciphertext"]
+
+
+def test_aes_fips197_and_ctr_vectors(oracle):
+    import ctypes as C
+    out = C.create_string_buffer(16)
+    pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    oracle.lib().orc_aes_encrypt_block(bytes(range(16)), 16, pt, out)
+    assert out.raw.hex() == "69c4e0d86a7b0430d8cdb78070b4c55a"          # FIPS-197 C.1
+    oracle.lib().orc_aes_encrypt_block(bytes(range(32)), 32, pt, out)
+    assert out.raw.hex() == "8ea2b7ca516745bfeafc49904b496089"          # FIPS-197 C.3
+    # RFC 3686 test vector #2 (AES-128-CTR, 32 bytes): nonce|iv|counter=1 — same construction as provers.go:184-192
+    key = bytes.fromhex("7e24067817fae0d743d6ce1f32539163")
+    nonce12 = bytes.fromhex("006cb6dbc0543b59da48d90b")
+    ct = oracle.aes_ctr_xor(key, nonce12, 1, bytes(range(32)))
+    assert ct.hex() == "5104a106168a72d9790d41ee8edad388eb2e1efc46da57c8fce630df9141be28"
+
+
+def test_sha256_and_expand_message_xmd(oracle):
+    import ctypes as C
+    out = C.create_string_buffer(32)
+    oracle.lib().orc_sha256(b"abc", 3, out)
+    assert out.raw.hex() == hashlib.sha256(b"abc").hexdigest()
+    msg = bytes(range(200))
+    oracle.lib().orc_sha256(msg, len(msg), out)
+    assert out.raw.hex() == hashlib.sha256(msg).hexdigest()
+    # RFC 9380 K.1 (expand_message_xmd, SHA-256), msg "" and "abc", len 0x20
+    dst = b"QUUX-V01-CS02-with-expander-SHA256-128"
+    o = C.create_string_buffer(32)
+    oracle.lib().orc_expand_message_xmd(b"", 0, dst, len(dst), o, 32)
+    assert o.raw.hex() == "68a985b87eb6b46952128911f2a4412bbc302a9d759667f87f7a21d803f07235"
+    oracle.lib().orc_expand_message_xmd(b"abc", 3, dst, len(dst), o, 32)
+    assert o.raw.hex() == "d8ccab23b5985ccea865c6c97b6e5b8350e794e603b4b97902f53a8a0d605615"
+
+
+def test_r1cs_decoder_shapes(oracle):
+    # SURVEY App. F statistics of the shipped constraint systems
+    cs = oracle.R1CS(golden_bytes("r1cs.chacha20"))
+    assert (cs.n_wires, cs.n_constraints, cs.n_public, cs.n_secret, cs.n_instr, cs.n_levels, cs.n_calldata, cs.n_coeff) == \
+        (23281, 23617, 1153, 256, 23954, 163, 452112, 40)
+    assert cs.levels_are_permutation() and cs.n_commit == 0
+    a = oracle.R1CS(golden_bytes("r1cs.aes128"))
+    assert (a.n_wires, a.n_constraints, a.n_public, a.n_secret, a.n_instr, a.n_levels, a.n_calldata, a.n_coeff) == \
+        (73164, 74899, 142, 16, 78430, 441, 1268533, 5400)
+    assert a.levels_are_permutation() and (a.n_commit, a.n_committed, a.commit_wire) == (1, 14629, 66179)
+    b = oracle.R1CS(golden_bytes("r1cs.aes256"))
+    assert (b.n_wires, b.n_constraints, b.n_instr, b.n_levels, b.n_calldata) == (97148, 99435, 104106, 462, 1680937)
+    assert b.levels_are_permutation() and (b.n_commit, b.n_committed, b.commit_wire) == (1, 19797, 89251)
+
+
+def test_key_decoder_shapes(chacha_oracle):
+    cs, pk, vk = chacha_oracle
+    assert (pk.n, pk.nA, pk.nB, pk.nZ, pk.nK, pk.nB2, pk.n_wires, pk.n_ck) == (32768, 22001, 12529, 32767, 22128, 12529, 23281, 0)
+    assert vk.nK == 1153
+
+
+def test_chacha_kat_every_stage_and_proof_bytes(oracle, chacha_oracle):
+    cs, pk, vk = chacha_oracle
+    proof, ct, d = oracle.prove(cs, pk, "chacha20", KAT["key"], KAT["nonce"], KAT["counter"], KAT["input"], 0, 0, dump=True)
+    assert ct == KAT["ciphertext"]
+    assert hashlib.sha256(d["W"]).hexdigest() == KAT["sha256_W"]
+    assert hashlib.sha256(d["A"] + d["B"] + d["C"]).hexdigest() == KAT["sha256_abc"]
+    assert hashlib.sha256(d["h"][: 32 * 32767]).hexdigest() == KAT["sha256_h"]
+    assert d["h"][32 * 32767:] == bytes(32)          # divisibility: deg H <= n-2
+    assert proof.hex() == KAT["proofs"][(0, 0)]
+    sig = ct + KAT["nonce"] + KAT["counter"].to_bytes(4, "little") + KAT["input"]
+    assert oracle.verify(vk, "chacha20", proof, sig)          # pairing check against the reference's vk.chacha20
+
+
+def test_chacha_kat_nonzero_randomness_and_verifier_rejections(oracle, chacha_oracle):
+    cs, pk, vk = chacha_oracle
+    (r, s), want = [kv for kv in KAT["proofs"].items() if kv[0] != (0, 0)][0]
+    proof, ct = oracle.prove(cs, pk, "chacha20", KAT["key"], KAT["nonce"], KAT["counter"], KAT["input"], r, s)
+    assert proof.hex() == want
+    sig = ct + KAT["nonce"] + KAT["counter"].to_bytes(4, "little") + KAT["input"]
+    assert oracle.verify(vk, "chacha20", proof, sig)
+    for pos in (0, 70, 77, 100):                      # flipped ciphertext / nonce / counter / plaintext bit
+        bad = bytearray(sig); bad[pos] ^= 1
+        assert not oracle.verify(vk, "chacha20", proof, bytes(bad))
+    badp = bytearray(proof); badp[5] ^= 1
+    assert not oracle.verify(vk, "chacha20", bytes(badp), sig)
+    assert not oracle.verify(vk, "chacha20", proof, sig[:-1])
+
+
+def test_chacha_random_inputs_verify_like_TestFullChaCha20(oracle, chacha_oracle):
+    # libraries/core_test.go:130-172: random key/nonce/plaintext, counter=1, pass criterion = verifier accepts
+    cs, pk, vk = chacha_oracle
+    rnd = random.Random(7)
+    key, nonce, pt = rnd.randbytes(32), rnd.randbytes(12), rnd.randbytes(64)
+    r, s = rnd.getrandbits(250), rnd.getrandbits(250)
+    proof, ct = oracle.prove(cs, pk, "chacha20", key, nonce, 1, pt, r, s)
+    assert len(proof) == 164
+    assert oracle.verify(vk, "chacha20", proof, ct + nonce + (1).to_bytes(4, "little") + pt)
+
+
+@pytest.mark.parametrize("name,cipher,keylen,counter", [("aes128", "aes-128-ctr", 16, 2), ("aes256", "aes-256-ctr", 32, 10)])
+def test_aes_solver_satisfies_every_constraint(oracle, name, cipher, keylen, counter):
+    # pk.aes* are missing from the reference (.MISSING_LARGE_BLOBS), so AES is pinned at the solver level only:
+    # all constraints hold for a correct ciphertext, for any mask / commitment value.
+    cs = oracle.R1CS(golden_bytes("r1cs." + name))
+    rnd = random.Random(11)
+    key, nonce, pt = rnd.randbytes(keylen), rnd.randbytes(12), rnd.randbytes(64)
+    rc, ct = cs.solve(cipher, key, nonce, counter, pt, mask=(12345).to_bytes(32, "big"), commit=(777).to_bytes(32, "big"), dump=False)
+    assert rc == 0
+    assert ct == oracle.aes_ctr_xor(key, nonce, counter, pt)
+    # counter > 2^32-5 is unprovable: the circuit asserts counter+b <= 2^32-1 (circuits/aesV2/aes128.go:41-53)
+    rc, _ = cs.solve(cipher, key, nonce, 0xFFFFFFFE, pt, dump=False)
+    assert rc != 0
