@@ -19,7 +19,7 @@ CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
 ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
 
 EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw",
-           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms"]
+           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_msm_z_kernel_ms"]
 
 
 class GoSlice(C.Structure):
@@ -62,6 +62,8 @@ def lib():
         L.gsc_describe.restype = C.c_size_t
         L.gsc_describe.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t]
         L.gsc_last_stage_ms.argtypes = [C.c_ubyte, C.POINTER(C.c_float)]
+        L.gsc_last_msm_z_kernel_ms.restype = C.c_float
+        L.gsc_last_msm_z_kernel_ms.argtypes = [C.c_ubyte, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.enforce_binding()
         _lib = L
     return _lib
@@ -152,3 +154,10 @@ def last_stage_ms(algorithm_id: int):
     if lib().gsc_last_stage_ms(algorithm_id, arr) != 0:
         return None
     return dict(zip(("witness", "quotient", "msm", "assembly"), list(arr)))
+
+
+def last_msm_z_kernel(algorithm_id: int):
+    """(milliseconds, proofs in the launch, bases per proof) of the dominant kernel in the last batch."""
+    b, nb = C.c_size_t(0), C.c_size_t(0)
+    ms = lib().gsc_last_msm_z_kernel_ms(algorithm_id, C.byref(b), C.byref(nb))
+    return float(ms), b.value, nb.value

@@ -286,6 +286,11 @@ size_t gsc_describe(GoUint8 algorithmID, char* out, size_t cap) {
     std::string s = a ? a->describe() : std::string("not initialised");
     size_t n = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(out, s.data(), n); out[n] = 0; return n;
 }
+float gsc_last_msm_z_kernel_ms(GoUint8 algorithmID, size_t* batch, size_t* nbases) {
+    if (algorithmID > 2) return -1.f;
+    Algorithm* a = lookup(algorithmID); if (!a) return -1.f;
+    return a->last_msm_z_kernel_ms(batch, nbases);
+}
 int gsc_last_stage_ms(GoUint8 algorithmID, float out[4]) {
     if (algorithmID > 2) return -1;
     Algorithm* a = lookup(algorithmID); if (!a) return -1;

@@ -72,8 +72,8 @@ class AlgorithmImpl {
     bool has_commitment = false;
     std::mutex mu;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {};
-    float stage_ms[4] = {0, 0, 0, 0};
+    hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
+    float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
     size_t table_bytes = 0;
 
     // program
@@ -228,9 +228,11 @@ class AlgorithmImpl {
         d_sumA.alloc(B); d_sumB1.alloc(B); d_sumK.alloc(B); d_sumZ.alloc(B); d_sumB2.alloc(B); d_tmp.alloc(2 * B);
     }
 
-    void run_msm_g1(const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum) {
+    void run_msm_g1(const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
         MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, set.nslices, d_part1a.p};
+        if (timed) HIP_CHECK(hipEventRecord(ev[5], stream));
         launch_msm_g1(a, stream);
+        if (timed) HIP_CHECK(hipEventRecord(ev[6], stream));
         G1Xyzz* src = d_part1a.p; G1Xyzz* alt = d_part1b.p; size_t ns = set.nslices;
         for (;;) {
             const size_t groups = (ns + 63) / 64;
@@ -297,7 +299,7 @@ class AlgorithmImpl {
         run_msm_g1(mB1, d_W.p, 1, B, d_sumB1.p);
         run_msm_g2(mB2, d_W.p, 1, B, d_sumB2.p);
         run_msm_g1(mK, d_W.p, 1, B, d_sumK.p);
-        run_msm_g1(mZ, d_A.p, 0, B, d_sumZ.p);
+        run_msm_g1(mZ, d_A.p, 0, B, d_sumZ.p, true);
         HIP_CHECK(hipEventRecord(ev[3], stream));
         // 4. assembly
         launch_finalize(d_sumA.p, d_sumB1.p, d_sumB2.p, d_sumK.p, d_sumZ.p, d_rs.p, B, d_out.p, d_flags.p, d_tmp.p, stream);
@@ -308,6 +310,7 @@ class AlgorithmImpl {
         HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, B * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]); stage_ms[k] = ms; }
+        (void)hipEventElapsedTime(&msm_z_kernel_ms, ev[5], ev[6]); last_batch = B;
         for (size_t i = 0; i < n; i++) serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], results[i]);
     }
 
@@ -342,6 +345,7 @@ Algorithm::~Algorithm() = default;
 Cipher Algorithm::cipher() const { return impl_->cipher; }
 size_t Algorithm::max_batch() const { return impl_->cap; }
 void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impl_->stage_ms[i]; }
+float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impl_->last_batch; if (nbases) *nbases = impl_->mZ.nbases; return impl_->msm_z_kernel_ms; }
 std::string Algorithm::describe() const {
     char buf[512];
     snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu",

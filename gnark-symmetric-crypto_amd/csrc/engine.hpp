@@ -50,6 +50,9 @@ class Algorithm {
     std::string describe() const;    // sizes, table memory — for logs / DESIGN numbers
     // raw timing of the last prove_batch, milliseconds per stage (solve, ntt, msm, finalize), device events
     void last_stage_ms(float out[4]) const;
+    // HIP-event duration of the dominant kernel (k_msm<Fp> over the Z tables) in the last batch, the padded batch it ran on
+    // and the number of bases it covered
+    float last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const;
   private:
     std::unique_ptr<AlgorithmImpl> impl_;
 };

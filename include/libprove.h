@@ -67,6 +67,9 @@ extern long long gsc_debug_vector(int which, uint8_t *out, size_t cap);
 extern size_t gsc_describe(GoUint8 algorithmID, char *out, size_t cap);
 /* Device milliseconds of the four stages (witness, quotient, msm, assembly) of the last batch of that algorithm. */
 extern int gsc_last_stage_ms(GoUint8 algorithmID, float out[4]);
+/* HIP-event milliseconds of the dominant kernel (Z-table MSM gather-accumulate) in the last batch; *batch = proofs the
+ * launch covered (padded to 64), *nbases = fixed bases per proof.  Used by bench.py for the roofline line. */
+extern float gsc_last_msm_z_kernel_ms(GoUint8 algorithmID, size_t *batch, size_t *nbases);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,138 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the libprove C-ABI, against the
+CPU oracle on the same inputs, against the committed golden vectors, and through size-independent properties
+(every proof must verify under the reference's vk.chacha20) at the benchmark's batch size."""
+import base64
+import hashlib
+import json
+import random
+
+import pytest
+
+from conftest import KAT, golden_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(key, nonce, counter, pt, cipher="chacha20"):
+    return {"cipher": cipher, "key": list(key), "nonce": list(nonce), "counter": counter, "input": list(pt)}
+
+
+def _signals(ct, nonce, counter, pt):
+    return ct + nonce + counter.to_bytes(4, "little") + pt          # core_test.go:158-163
+
+
+def test_native_code_is_loaded(gsc_chacha):
+    maps = open("/proc/self/maps").read()
+    assert "libprove.so" in maps
+    assert "tables=" in gsc_chacha.describe(gsc_chacha.CHACHA20)
+
+
+def test_kat_pipeline_stages_match_golden_vectors(gsc_chacha):
+    g = gsc_chacha
+    g.set_deterministic_randomness(0, 0, 0)
+    d = g.debug_prove(_params(KAT["key"], KAT["nonce"], KAT["counter"], KAT["input"]))
+    g.set_deterministic_randomness(None)
+    be = lambda vals: b"".join(v.to_bytes(32, "big") for v in vals)
+    assert hashlib.sha256(be(d["W"])).hexdigest() == KAT["sha256_W"]
+    assert hashlib.sha256(be(d["A"]) + be(d["B"]) + be(d["C"])).hexdigest() == KAT["sha256_abc"]
+    n = len(d["h"]); L = n.bit_length() - 1
+    nat = [d["h"][int(format(j, "0%db" % L)[::-1], 2)] for j in range(n)]     # device order is bit-reversed (pk.G1.Z order)
+    assert nat[n - 1] == 0
+    assert hashlib.sha256(be(nat[: n - 1])).hexdigest() == KAT["sha256_h"]
+
+
+@pytest.mark.parametrize("rs", list(KAT["proofs"].keys()))
+def test_kat_proof_bytes(gsc_chacha, rs):
+    g = gsc_chacha
+    g.set_deterministic_randomness(rs[0], rs[1], 0)
+    out = json.loads(g.prove(_params(KAT["key"], KAT["nonce"], KAT["counter"], KAT["input"])))
+    g.set_deterministic_randomness(None)
+    assert base64.b64decode(out["publicSignals"]) == KAT["ciphertext"]
+    assert base64.b64decode(out["proof"]["proofJson"]).hex() == KAT["proofs"][rs]
+    assert list(out.keys()) == ["proof", "publicSignals"]             # field order of OutputParams (prove_impl.go:49-52)
+
+
+def test_random_inputs_bit_exact_vs_oracle_and_verify(gsc_chacha, oracle, chacha_oracle):
+    g = gsc_chacha; cs, pk, vk = chacha_oracle
+    rnd = random.Random(2024)
+    r, s = rnd.getrandbits(253), rnd.getrandbits(253)
+    cases = [(rnd.randbytes(32), rnd.randbytes(12), rnd.getrandbits(32), rnd.randbytes(64)) for _ in range(5)]
+    cases.append((bytes(32), bytes(12), 0, bytes(64)))                  # all-zero edge
+    cases.append((b"\xff" * 32, b"\xff" * 12, 0xFFFFFFFF, b"\xff" * 64))  # all-ones / max counter edge
+    g.set_deterministic_randomness(r, s, 0)
+    outs = g.prove_batch([_params(*c) for c in cases])
+    g.set_deterministic_randomness(None)
+    for c, out in zip(cases, outs):
+        proof = base64.b64decode(out["proof"]["proofJson"]); ct = base64.b64decode(out["publicSignals"])
+        want, want_ct = oracle.prove(cs, pk, "chacha20", c[0], c[1], c[2], c[3], r, s)
+        assert ct == want_ct
+        assert proof == want
+        assert oracle.verify(vk, "chacha20", proof, _signals(ct, c[1], c[2], c[3]))
+
+
+def test_csprng_proofs_differ_and_verify_like_TestFullChaCha20(gsc_chacha, oracle, chacha_oracle):
+    # libraries/core_test.go:130-172: random inputs, counter = 1, base64 byte fields, verifier must accept
+    g = gsc_chacha; _, _, vk = chacha_oracle
+    rnd = random.Random(5)
+    key, nonce, pt = rnd.randbytes(32), rnd.randbytes(12), rnd.randbytes(64)
+    p = {"cipher": "chacha20", "key": base64.b64encode(key).decode(), "nonce": base64.b64encode(nonce).decode(), "counter": 1,
+         "input": base64.b64encode(pt).decode()}
+    a = json.loads(g.prove(p)); b = json.loads(g.prove(p))
+    pa, pb = base64.b64decode(a["proof"]["proofJson"]), base64.b64decode(b["proof"]["proofJson"])
+    assert pa != pb and len(pa) == len(pb) == 164                       # fresh (r, s) per proof
+    for out, proof in ((a, pa), (b, pb)):
+        assert oracle.verify(vk, "chacha20", proof, _signals(base64.b64decode(out["publicSignals"]), nonce, 1, pt))
+
+
+def test_full_batch_ragged_size_all_verify(gsc_chacha, oracle, chacha_oracle):
+    # BASELINE config size per GPU step (1024) plus a ragged tail (not a multiple of the 64-lane solver width):
+    # every proof must verify under the reference's vk, and the binary path must agree with the JSON path.
+    g = gsc_chacha; cs, pk, vk = chacha_oracle
+    n = 1024 + 37
+    rnd = random.Random(99)
+    recs = b"".join(rnd.randbytes(44) + rnd.getrandbits(32).to_bytes(4, "little") + rnd.randbytes(64) for _ in range(n))
+    r, s = rnd.getrandbits(250), rnd.getrandbits(250)
+    g.set_deterministic_randomness(r, s, 0)
+    ok, proofs, lens, cts = g.prove_raw(g.CHACHA20, recs, n)
+    i = n - 1
+    rec = recs[112 * i:112 * (i + 1)]
+    single = json.loads(g.prove(_params(rec[:32], rec[32:44], int.from_bytes(rec[44:48], "little"), rec[48:])))
+    g.set_deterministic_randomness(None)
+    assert ok == n and set(lens) == {164}
+    assert base64.b64decode(single["proof"]["proofJson"]) == proofs[196 * i:196 * i + 164]
+    assert len({proofs[196 * k:196 * k + 164] for k in range(n)}) == n
+    check = list(range(0, n, 97)) + [63, 64, 1023, 1024, n - 1]
+    for k in check:
+        rec = recs[112 * k:112 * (k + 1)]
+        key, nonce, ctr, pt = rec[:32], rec[32:44], int.from_bytes(rec[44:48], "little"), rec[48:]
+        proof, ct = proofs[196 * k:196 * k + 164], cts[64 * k:64 * k + 64]
+        assert ct == oracle.chacha20_xor(key, nonce, ctr, pt)
+        assert oracle.verify(vk, "chacha20", proof, _signals(ct, nonce, ctr, pt)), k
+    # bit-exact against the oracle on a few of them
+    for k in (0, 64, n - 1):
+        rec = recs[112 * k:112 * (k + 1)]
+        want, _ = oracle.prove(cs, pk, "chacha20", rec[:32], rec[32:44], int.from_bytes(rec[44:48], "little"), rec[48:], r, s)
+        assert proofs[196 * k:196 * k + 164] == want
+
+
+def test_error_reporting_matches_reference_conventions(gsc_chacha):
+    g = gsc_chacha
+    # TestPanic (core_test.go:120-128): bad cipher name and an array where uint32 is expected -> the decode error object
+    bad = json.loads(g.prove({"cipher": "aes-256-ctr1", "key": [0] * 32, "nonce": [0] * 12, "counter": [0, 1], "input": [0] * 64}))
+    assert bad["Field"] == "counter" and bad["Value"] == "array" and bad["Struct"] == "InputParams" and "proof" not in bad
+    assert json.loads(g.prove({"cipher": "aes-256-ctr1", "key": [], "nonce": [], "counter": 0, "input": []})) == "could not find prover foraes-256-ctr1"
+    assert json.loads(g.prove({"cipher": "aes-128-ctr", "key": [0] * 16, "nonce": [0] * 12, "counter": 0, "input": [0] * 64})) == \
+        "proving params are not initialized for cipher: aes-128-ctr"
+    assert json.loads(g.prove({"cipher": "chacha20", "key": [0] * 31, "nonce": [0] * 12, "counter": 0, "input": [0] * 64})) == "key length must be 32: 31"
+    assert json.loads(g.prove({"cipher": "chacha20", "key": [0] * 32, "nonce": [0] * 11, "counter": 0, "input": [0] * 64})) == "nonce length must be 12: 11"
+    assert json.loads(g.prove({"cipher": "chacha20", "key": [0] * 32, "nonce": [0] * 12, "counter": 0, "input": [0] * 65})) == "plaintext length must be 64: 65"
+    assert "Offset" in json.loads(g.prove(b'{"cipher": "chacha20", '))
+    assert json.loads(g.prove({"cipher": "chacha20", "key": [0] * 32, "nonce": [0] * 12, "counter": 2 ** 32, "input": [0] * 64}))["Value"] == "number 4294967296"
+    # unknown keys are ignored, key matching is case-insensitive (encoding/json)
+    ok = json.loads(g.prove({"Cipher": "chacha20", "KEY": [1] * 32, "nonce": [2] * 12, "counter": 5, "input": [3] * 64, "extra": {"x": 1}}))
+    assert "proof" in ok
+    # InitAlgorithm is idempotent and rejects unknown ids (prove_impl.go:74-76, :113)
+    assert g.init_algorithm(g.CHACHA20, b"", b"") is True
+    assert g.init_algorithm(7, b"x", b"y") is False
+    # garbage key material for a not-yet-initialised algorithm is refused, never crashes
+    assert g.init_algorithm(g.AES_128, b"\x00" * 100, b"\x01" * 100) is False

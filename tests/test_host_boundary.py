@@ -1,0 +1,88 @@
+"""CPU tests of the drop-in boundary: libprove.so builds, loads, exports every symbol include/libprove.h declares,
+decodes JSON like encoding/json, and refuses to work without a GPU (no CPU fallback, no oracle behind it)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, golden_bytes
+
+
+def test_library_exports_every_declared_symbol(gsc):
+    hdr = open(os.path.join(ROOT, "include", "libprove.h")).read()
+    declared = set(re.findall(r"extern\s+[\w\s\*]+?\b(\w+)\s*\(", hdr))
+    assert {"enforce_binding", "InitAlgorithm", "Free", "Prove"} <= declared
+    lib = gsc.lib()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert declared == set(gsc.EXPORTS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", gsc.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert exported == declared          # nothing else leaks out of the shared object
+
+
+def test_product_never_links_the_oracle(gsc):
+    out = subprocess.check_output(["ldd", gsc.LIB_PATH]).decode()
+    assert "liboracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gnark-symmetric-crypto_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_without_gpu_init_fails_loudly_and_prove_reports_uninitialised(gsc, capfd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert gsc.init_algorithm(gsc.CHACHA20, golden_bytes("pk.chacha20"), golden_bytes("r1cs.chacha20")) is False
+    out = json.loads(gsc.prove({"cipher": "chacha20", "key": [0] * 32, "nonce": [0] * 12, "counter": 0, "input": [0] * 64}))
+    assert out == "proving params are not initialized for cipher: chacha20"
+    assert gsc.prove_raw(gsc.CHACHA20, bytes(112), 1)[0] == -1
+
+
+def test_json_decoding_rules_follow_encoding_json(gsc):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU tests")
+    p = gsc.prove
+    # decode errors are reported before the cipher lookup, as an UnmarshalTypeError-shaped object
+    e = json.loads(p(b'{"cipher":"chacha20","key":"not base64!","nonce":[],"counter":1,"input":[]}'))
+    assert isinstance(e, int)                                           # base64.CorruptInputError marshals as its offset
+    e = json.loads(p(b'{"cipher":"chacha20","key":[1,2,256],"nonce":[],"counter":1,"input":[]}'))
+    assert e["Value"] == "number 256" and e["Field"] == "key"
+    e = json.loads(p(b'{"cipher":"chacha20","key":[1],"nonce":[],"counter":-1,"input":[]}'))
+    assert e["Value"] == "number -1" and e["Field"] == "counter"
+    e = json.loads(p(b'{"cipher":"chacha20","key":[1],"nonce":[],"counter":1.5,"input":[]}'))
+    assert e["Value"] == "number 1.5"
+    e = json.loads(p(b'{"cipher":5}'))
+    assert e["Value"] == "number" and e["Field"] == "cipher"
+    assert json.loads(p(b'[1,2]'))["Value"] == "array"
+    assert json.loads(p(b'')) == {"Offset": 0}
+    assert json.loads(p(b'{"cipher":"chacha20"} x')) == {"Offset": 22}
+    assert json.loads(p(b'null')) == "runtime error: invalid memory address or nil pointer dereference"
+    assert json.loads(p(b'{"cipher":"nope"}')) == "could not find prover fornope"
+    assert json.loads(p(b'{"CIPHER":"<x>"}')) == "could not find prover for<x>"      # HTML-safe escaping is transparent to a JSON reader
+
+
+def test_solver_program_builder_and_key_parser_on_reference_files():
+    # Host-side decoders are compiled into a tiny CLI so they can be exercised without a GPU.
+    exe = os.path.join(ROOT, "build", "host_decode_check")
+    src = os.path.join(ROOT, "tools", "host_decode_check.cpp")
+    csrc = os.path.join(ROOT, "gnark-symmetric-crypto_amd", "csrc")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", csrc, src, os.path.join(csrc, "formats.cpp"), "-o", exe])
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        for name in ("r1cs.chacha20", "r1cs.aes128", "r1cs.aes256", "pk.chacha20"):
+            open(os.path.join(td, name), "wb").write(golden_bytes(name))
+        out = subprocess.check_output([exe, td]).decode()
+    rep = dict(l.split("=", 1) for l in out.split())
+    assert rep["chacha.instr"] == "23954" and rep["chacha.wires"] == "23281" and rep["chacha.constraints"] == "23617" and rep["chacha.inversions"] == "0"
+    assert rep["aes128.instr"] == "78430" and rep["aes128.inversions"] == "2080" and rep["aes128.tables"] == "5"
+    assert rep["aes256.instr"] == "104106" and rep["aes256.inversions"] == "2384"
+    assert rep["pk.A"] == "22001" and rep["pk.B"] == "12529" and rep["pk.Z"] == "32767" and rep["pk.K"] == "22128" and rep["pk.n"] == "32768"
+    assert rep["truncated.r1cs"] == "rejected" and rep["truncated.pk"] == "rejected"
