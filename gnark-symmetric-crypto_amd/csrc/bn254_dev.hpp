@@ -130,32 +130,41 @@ struct Field {
         for (int i = 0; i < 8; i++) t.l[i] = z ? 0u : t.l[i];
         return t;
     }
-    // Montgomery product a*b*R^-1 mod p, operand-scanning CIOS on 32-bit limbs.
+    // acc (96 bits: 64-bit pair + overflow word) += x * y.  One v_mad_u64_u32 whose carry-out feeds a v_addc: the
+    // compiler cannot express the carry-out of the 64-bit multiply-add from C, and without it every product costs
+    // 4-5 instructions (measured: 585 VALU instructions per Montgomery product from the C version, 291 of them v_mov).
+    DEVFN static void mac(uint64_t& acc, uint32_t& ovf, uint32_t x, uint32_t y) {
+        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(ovf) : "v"(x), "v"(y) : "vcc");
+    }
+    DEVFN static void mac_first(uint64_t& acc, uint32_t x, uint32_t y) {   // acc = x*y (no overflow possible)
+        acc = (uint64_t)x * y;
+    }
+    DEVFN static void shift(uint64_t& acc, uint32_t& ovf) { acc = (acc >> 32) | ((uint64_t)ovf << 32); ovf = 0; }
+    // Montgomery product a*b*R^-1 mod p: product scanning (FIPS), the reduction interleaved column by column.
     DEVMUL static E mul(const E& a, const E& b) {
-        uint32_t t[10];
+        uint32_t n[8];
 #pragma unroll
-        for (int i = 0; i < 10; i++) t[i] = 0;
+        for (int i = 0; i < 8; i++) n[i] = P::mod(i);
+        uint32_t m[8];
+        uint64_t acc = 0; uint32_t ovf = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t c = 0;
+        for (int k = 0; k < 8; k++) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                c += (uint64_t)a.l[j] * b.l[i] + t[j];
-                t[j] = (uint32_t)c; c >>= 32;
-            }
-            c += t[8]; t[8] = (uint32_t)c; t[9] = (uint32_t)(c >> 32);
-            uint32_t m = t[0] * P::ninv;
-            c = (uint64_t)m * P::mod(0) + t[0]; c >>= 32;
-#pragma unroll
-            for (int j = 1; j < 8; j++) {
-                c += (uint64_t)m * P::mod(j) + t[j];
-                t[j - 1] = (uint32_t)c; c >>= 32;
-            }
-            c += t[8]; t[7] = (uint32_t)c; t[8] = t[9] + (uint32_t)(c >> 32);
+            for (int i = 0; i < k; i++) { mac(acc, ovf, a.l[i], b.l[k - i]); mac(acc, ovf, m[i], n[k - i]); }
+            mac(acc, ovf, a.l[k], b.l[0]);
+            m[k] = (uint32_t)acc * P::ninv;
+            mac(acc, ovf, m[k], n[0]);
+            shift(acc, ovf);
         }
         E r;
 #pragma unroll
-        for (int i = 0; i < 8; i++) r.l[i] = t[i];
+        for (int k = 8; k < 16; k++) {
+#pragma unroll
+            for (int i = k - 7; i < 8; i++) { mac(acc, ovf, a.l[i], b.l[k - i]); mac(acc, ovf, m[i], n[k - i]); }
+            r.l[k - 8] = (uint32_t)acc;
+            shift(acc, ovf);
+        }
+        // a, b < p  =>  result < 2p < 2^255: the ninth word is zero
         return reduce_once(r);
     }
     DEVFN static E sqr(const E& a) { return mul(a, a); }

@@ -77,15 +77,15 @@ class AlgorithmImpl {
     size_t table_bytes = 0;
 
     // program
-    DevBuf<uint32_t> prog, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
-    size_t split_word = 0;
+    DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
+    uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; int has_div = 0;
     // NTT
     DevBuf<fe> tw_fwd, tw_inv, scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
     // MSM sets
     MsmSet<G1Aff> mA, mB1, mK, mZ; MsmSet<G2Aff> mB2;
     // batch buffers
     size_t cap = 0;
-    DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags; DevBuf<uint32_t> d_status;
+    DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags; DevBuf<uint32_t> d_status; DevBuf<unsigned long long> d_dbg;
     DevBuf<fe> d_W, d_A, d_B, d_C;
     DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
 
@@ -110,8 +110,10 @@ class AlgorithmImpl {
         if (cs.n_public - 1 + cs.n_secret != expect_in) throw std::runtime_error("r1cs: witness size does not match the cipher's circuit");
         if (cs.n_coeff() < 5 || memcmp(cs.coeff_limbs.data(), kSmallCoeffs, sizeof kSmallCoeffs)) throw std::runtime_error("r1cs: coefficient ids 0..4 are not 0,1,2,-1,-2");
         SolverProgram sp = build_solver_program(cs);
-        split_word = sp.split_word;
+        n_levels = (uint32_t)sp.n_levels; commit_level = (uint32_t)sp.commit_level; has_div = sp.n_inversions ? 1 : 0;
+        level_width.resize(n_levels); for (uint32_t l = 0; l < n_levels; l++) level_width[l] = sp.sched[2 + l] - sp.sched[1 + l];
         prog.alloc(sp.words.size()); prog.upload(sp.words.data(), sp.words.size(), stream);
+        sched.alloc(sp.sched.size()); sched.upload(sp.sched.data(), sp.sched.size(), stream);
         lookup_coeff.alloc(sp.lookup_coeff.size() ? sp.lookup_coeff.size() : 1);
         if (!sp.lookup_coeff.empty()) lookup_coeff.upload(sp.lookup_coeff.data(), sp.lookup_coeff.size(), stream);
         coeff.alloc(cs.n_coeff()); coeff_inv.alloc(cs.n_coeff());
@@ -220,7 +222,7 @@ class AlgorithmImpl {
 
     void alloc_batch(size_t B) {
         cap = B;
-        d_inputs.alloc(176 * B); d_rs.alloc(64 * B); d_out.alloc(256 * B); d_flags.alloc((B + 3) / 4 * 4); d_status.alloc(B);
+        d_dbg.alloc(2); d_inputs.alloc(176 * B); d_rs.alloc(64 * B); d_out.alloc(256 * B); d_flags.alloc((B + 3) / 4 * 4); d_status.alloc(B);
         d_W.alloc((n_wires + 4) * B); d_A.alloc(domain_n * B); d_B.alloc(domain_n * B); d_C.alloc(domain_n * B);
         size_t s1 = mA.nslices; for (size_t v : {mB1.nslices, mK.nslices, mZ.nslices}) if (v > s1) s1 = v;
         d_part1a.alloc(s1 * B); d_part1b.alloc((s1 + 63) / 64 * B);
@@ -281,9 +283,13 @@ class AlgorithmImpl {
         if (cipher == CHACHA20) launch_assign_chacha(d_inputs.p, d_W.p, B, stream);
         else launch_assign_aes(d_inputs.p, cipher == AES_128 ? 16 : 32, d_W.p, B, stream);
         launch_prep_rs(d_rs.p, d_W.p, n_wires, B, stream);
-        SolverArgs sa{prog.p, 0, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p, nullptr, nullptr, 0};
-        launch_solver(sa, stream);
+        HIP_CHECK(hipMemsetAsync(d_status.p, 0xFF, B * 4, stream));
+        SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p, nullptr, nullptr, has_div, env_int("GSC_DBG", 0), d_dbg.p};
+        if (sa.dbg & 32) HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 16, stream));
+        for (uint32_t l = 0; l < n_levels; l++) { sa.first_level = l; launch_solver_level(sa, level_width[l], stream); }
         HIP_CHECK(hipEventRecord(ev[1], stream));
+        if (sa.dbg & 32) { unsigned long long h[2]; HIP_CHECK(hipMemcpyAsync(h, d_dbg.p, 16, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream));
+            printf("solver wave0: %llu shader cycles, %llu x10ns -> %.0f MHz, %.1f us busy\n", h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[1] / 100.0); }
         if (dbg) {
             dbg->n_wires = n_wires; dbg->n_constraints = n_constraints; dbg->n = domain_n;
             fetch_column(d_W.p, n_wires, B, 0, dbg->W); fetch_column(d_A.p, n_constraints, B, 0, dbg->A);
@@ -317,7 +323,7 @@ class AlgorithmImpl {
     // gnark proof.WriteTo: Ar | Bs | Krs compressed, u32be nbCommitments, commitments, CommitmentPok
     void serialize(const uint8_t* o, uint8_t flags, uint32_t status, ProofResult& res) const {
         res.proof_len = 0; res.status = 0;
-        if (status) { res.status = 1; return; }
+        if (status != 0xFFFFFFFFu) { res.status = 1; return; }
         if (flags) { res.status = 2; return; }
         uint8_t* p = res.proof;
         auto g1 = [&](const uint8_t* xy, uint8_t* dst) {

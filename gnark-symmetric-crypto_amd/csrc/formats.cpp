@@ -266,7 +266,14 @@ SolverProgram build_solver_program(const R1csFile& cs) {
         for (size_t k = 0; k < 256; k++) { if (e[3 * k] != 1 || e[3 * k + 2] != WIRE_CONST) throw std::runtime_error("solver: non-constant lookup entry"); sp.lookup_coeff.push_back(e[3 * k + 1]); }
     }
     auto& W = sp.words;
-    auto check_wire = [&](uint32_t wid) { if (wid != WIRE_CONST && (wid >= nw || !solved[wid])) throw std::runtime_error("solver: instruction reads an unsolved wire"); };
+    std::vector<uint32_t> wire_level(nw, 0);          // level at which a wire's value becomes available (inputs: 0)
+    std::vector<uint32_t> op_level, op_offset; size_t commit_op = (size_t)-1;
+    uint32_t cur_level = 0;                            // max wire_level over the wires the current op reads
+    auto check_wire = [&](uint32_t wid) {
+        if (wid == WIRE_CONST) return;
+        if (wid >= nw || !solved[wid]) throw std::runtime_error("solver: instruction reads an unsolved wire");
+        if (wire_level[wid] > cur_level) cur_level = wire_level[wid];
+    };
     auto check_coeff = [&](uint32_t cid) { if (cid >= cs.n_coeff()) throw std::runtime_error("solver: coefficient id out of range"); };
     auto copy_linexp = [&](const uint32_t* p, const uint32_t* end) -> size_t {
         if (p >= end || p + linexp_words(p) > end) throw std::runtime_error("solver: truncated linear expression");
@@ -280,15 +287,19 @@ SolverProgram build_solver_program(const R1csFile& cs) {
         const size_t ncd = end - cd;
         const BlueprintKind kind = cs.bp_kind[cs.blueprint[ii]];
         const size_t hdr_at = W.size();
+        cur_level = 0;
+        std::vector<uint32_t> produced;
         if (kind == BP_R1C) {
             if (ncd < 4) throw std::runtime_error("solver: short R1C");
             const uint32_t cnt[3] = {cd[1], cd[2], cd[3]};
             if (4 + 2 * (size_t(cnt[0]) + cnt[1] + cnt[2]) != ncd) throw std::runtime_error("solver: R1C length mismatch");
             if (cs.constraint_off[ii] >= cs.n_constraints) throw std::runtime_error("solver: constraint offset out of range");
-            uint32_t loc = 0, uw = 0, uc = 0; uint32_t kept[3] = {0, 0, 0};
-            W.insert(W.end(), {0u, 0u, 0u, 0u, 0u, cs.constraint_off[ii], 0u, 0u});
+            uint32_t loc = 0, uw = 0, uc = 0;
+            W.insert(W.end(), {0u, 0u, cs.constraint_off[ii], 0u, 0u});
             const uint32_t* t = cd + 4;
-            for (int side = 0; side < 3; side++)
+            for (int side = 0; side < 3; side++) {
+                const size_t cnt_at = W.size(); uint32_t kept = 0;
+                W.push_back(0u);
                 for (uint32_t k = 0; k < cnt[side]; k++, t += 2) {
                     check_coeff(t[0]);
                     if (t[1] != WIRE_CONST && t[1] < nw && !solved[t[1]]) {
@@ -296,11 +307,12 @@ SolverProgram build_solver_program(const R1csFile& cs) {
                         loc = side + 1; uw = t[1]; uc = t[0]; continue;
                     }
                     check_wire(t[1]);
-                    W.push_back(t[0]); W.push_back(t[1]); kept[side]++;
+                    W.push_back(t[0]); W.push_back(t[1]); kept++;
                 }
-            W[hdr_at + 1] = loc; W[hdr_at + 2] = kept[0]; W[hdr_at + 3] = kept[1]; W[hdr_at + 4] = kept[2];
-            W[hdr_at + 6] = uw; W[hdr_at + 7] = uc;
-            if (loc) solved[uw] = 1;
+                W[cnt_at] = kept;
+            }
+            W[hdr_at + 1] = loc; W[hdr_at + 3] = uw; W[hdr_at + 4] = uc;
+            if (loc) { solved[uw] = 1; produced.push_back(uw); }
             if (loc == 1 || loc == 2) sp.n_inversions++;
             W[hdr_at] = OP_R1C | uint32_t((W.size() - hdr_at) << 8);
         } else if (kind == BP_HINT) {
@@ -342,9 +354,10 @@ SolverProgram build_solver_program(const R1csFile& cs) {
                 if (!cs.has_commitment || nout != 1 || o0 != cs.commit_wire) throw std::runtime_error("solver: unexpected commitment hint");
                 for (uint32_t k = 0; k < nin; k++) { const uint32_t* q = in; (void)q; }
                 W.insert(W.end(), {0u, o0, nout}); W[hdr_at] = OP_COMMIT;
-                sp.split_word = hdr_at;
+                for (uint32_t w : cs.commit_private) check_wire(w);          // the commitment reads every committed wire
+                commit_op = op_offset.size();
             } else throw std::runtime_error("solver: unknown hint id " + std::to_string(hid));
-            for (uint32_t k = 0; k < nout; k++) solved[o0 + k] = 1;
+            for (uint32_t k = 0; k < nout; k++) { solved[o0 + k] = 1; produced.push_back(o0 + k); }
             W[hdr_at] |= uint32_t((W.size() - hdr_at) << 8);
         } else {   // BP_LOOKUP
             if (ncd < 3) throw std::runtime_error("solver: short lookup");
@@ -356,14 +369,34 @@ SolverProgram build_solver_program(const R1csFile& cs) {
             const uint32_t* q = cd + 3;
             for (uint32_t k = 0; k < nin; k++) q += copy_linexp(q, end);
             if (q != end) throw std::runtime_error("solver: lookup length mismatch");
-            for (uint32_t k = 0; k < nin; k++) solved[o0 + k] = 1;
+            for (uint32_t k = 0; k < nin; k++) { solved[o0 + k] = 1; produced.push_back(o0 + k); }
             W[hdr_at] = OP_LOOKUP | uint32_t((W.size() - hdr_at) << 8);
         }
         if ((W.size() - hdr_at) >> 24) throw std::runtime_error("solver: instruction too long");
+        for (uint32_t w : produced) wire_level[w] = cur_level + 1;
+        op_level.push_back(cur_level); op_offset.push_back((uint32_t)hdr_at);
         sp.n_ops++;
     }
     for (size_t i = 0; i < nw; i++) if (!solved[i]) throw std::runtime_error("solver: wire " + std::to_string(i) + " is never assigned");
     W.push_back(OP_END | (1u << 8));
+    W.insert(W.end(), 64, 0u);
+    // level schedule (counting sort by level; the commitment op gets a level of its own)
+    uint32_t nlev = 0; for (uint32_t l : op_level) if (l + 1 > nlev) nlev = l + 1;
+    std::vector<std::vector<uint32_t>> by_level(nlev);
+    for (size_t i = 0; i < op_level.size(); i++) if (i != commit_op) by_level[op_level[i]].push_back(op_offset[i]);
+    std::vector<std::vector<uint32_t>> levels;
+    sp.commit_level = (size_t)-1;
+    for (uint32_t l = 0; l < nlev; l++) {
+        if (!by_level[l].empty()) levels.push_back(by_level[l]);
+        if (commit_op != (size_t)-1 && op_level[commit_op] == l) { sp.commit_level = levels.size(); levels.push_back({op_offset[commit_op]}); }
+    }
+    sp.n_levels = levels.size();
+    if (sp.commit_level == (size_t)-1) sp.commit_level = sp.n_levels;
+    sp.sched.push_back((uint32_t)sp.n_levels);
+    uint32_t run = 0;
+    for (auto& l : levels) { sp.sched.push_back(run); run += (uint32_t)l.size(); if (l.size() > sp.max_level_width) sp.max_level_width = l.size(); }
+    sp.sched.push_back(run);
+    for (auto& l : levels) sp.sched.insert(sp.sched.end(), l.begin(), l.end());
     return sp;
 }
 

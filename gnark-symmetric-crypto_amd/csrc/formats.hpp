@@ -57,11 +57,13 @@ struct PkFile {
 PkFile parse_pk(const uint8_t* buf, size_t len);
 
 // ---- device solver program (built once per algorithm from the R1CS instruction list) ----
-// Word stream; every op starts with a header word: opcode | (total_words << 8).
+// Word stream; every op starts with a header word: opcode | (total_words << 8).  The stream is padded with 64 zero
+// words so that a wave may always fetch a full 64-word window starting at any op.
 enum SolverOp : uint32_t {
     OP_END = 0,
-    OP_R1C = 1,       // [hdr, loc, nL, nR, nO, constraint, unk_wire, unk_coeff, terms(cid,wid)...]   loc 0 none,1 L,2 R,3 O
-    OP_NBITS = 2,     // [hdr, out0, nOut, nTerms, terms...]
+    OP_R1C = 1,       // [hdr, loc, constraint, unk_wire, unk_coeff, L, R, O]   loc 0 none,1 L,2 R,3 O; L/R/O = linear expressions
+                      //   (n, then n x (cid, wid)) without the term of the wire being solved
+    OP_NBITS = 2,     // [hdr, out0, nOut, linear expression]
     OP_COUNT = 3,     // [hdr, out0, nOut(=nTable), nVars, nQueries, then (nTable+nQueries)*nVars linear expressions: n, terms...]
     OP_LOOKUP = 4,    // [hdr, out0, nIn, table_id, then nIn linear expressions]
     OP_RANDOMIZE = 5, // [hdr, out0, nOut]
@@ -72,8 +74,12 @@ struct SolverProgram {
     // lookup tables flattened: table t entry e -> coefficient id (entries are constant expressions)
     std::vector<uint32_t> lookup_coeff;      // n_tables * 256
     size_t n_tables = 0;
-    // index of the OP_COMMIT op's word offset (program is split there when a commitment exists): [0,split) then [split,end)
-    size_t split_word = 0;
+    // Level schedule (ops of one level are mutually independent; a level only reads wires produced by earlier levels):
+    // sched = [n_levels, level_start[0..n_levels], op_word_offset[0..n_ops)] with ops listed level by level.
+    // When the circuit has a commitment, its OP_COMMIT sits alone in level `commit_level`; the host runs levels
+    // [0, commit_level), computes the commitment, then runs [commit_level, n_levels).  Otherwise commit_level == n_levels.
+    std::vector<uint32_t> sched;
+    size_t n_levels = 0, commit_level = 0, max_level_width = 0;
     size_t n_ops = 0, n_inversions = 0;
 };
 SolverProgram build_solver_program(const R1csFile& cs);

@@ -52,11 +52,17 @@ __device__ __forceinline__ bool sign_normalise(fe& s) {
     return gt;
 }
 
+// limb i of s, i wave-uniform but not a compile-time constant: a select chain keeps s in registers
+// (indexing s.l[] dynamically would push the scalar into scratch memory)
+__device__ __forceinline__ uint32_t limb_at(const fe& s, uint32_t i) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r = i == (uint32_t)k ? s.l[k] : r;
+    return r;
+}
 __device__ __forceinline__ uint32_t bits_at(const fe& s, uint32_t pos, uint32_t c) {
-    if (pos >= 256) return 0;
     const uint32_t w = pos >> 5, sh = pos & 31;
-    uint64_t v = s.l[w];
-    if (w + 1 < 8) v |= (uint64_t)s.l[w + 1] << 32;
+    const uint64_t v = (uint64_t)limb_at(s, w) | ((uint64_t)limb_at(s, w + 1) << 32);
     return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 

@@ -6,6 +6,9 @@
 //
 // Layout: W[wire][proof], A/B/C[constraint][proof], 32-byte elements: the 64 lanes of a wave read and write
 // 2 KiB contiguous per access (coalesced), and the instruction words are wave-uniform (scalar registers).
+// Parallelism inside a proof comes from the circuit's level structure (ChaCha20-V3: 163 levels of ~147 mutually
+// independent instructions): one launch per level, one wave per (64 proofs, instruction), so a 1024-proof batch
+// puts ~2 400 waves on the chip per level; the kernel boundary is the barrier between levels.
 #include "kernels.hpp"
 #include "formats.hpp"
 
@@ -14,64 +17,168 @@ using namespace bn254;
 
 namespace {
 
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+constexpr int WPB = 4;    // waves per workgroup; every wave executes one instruction of the level for 64 proofs
 
-struct SolverCtx {
-    const fe* coeff; const fe* W; size_t batch; size_t p;
+// A wave-wide 64-word window onto the instruction stream: one coalesced load, fields are read with v_readlane
+// (the op and all of its fields are wave-uniform, so they live in scalar registers).
+struct Window {
+    const uint32_t* prog; uint32_t base; uint32_t w; uint32_t lane;
+    __device__ __forceinline__ void load(uint32_t b) { base = b; w = prog[b + lane]; }
+    __device__ __forceinline__ uint32_t get(uint32_t k) {
+        if (k - base >= 64u) load(k);
+        return (uint32_t)__builtin_amdgcn_readlane((int)w, (int)(k - base));
+    }
+    // k must be inside the window.  Unlike get() this has no reload path, so the compiler can prove the window
+    // register is not pending and does NOT put an s_waitcnt vmcnt(0) in front of it — which matters because that
+    // wait would also drain the wire loads issued in between (measured: it serialised every term, ~1.2 us each).
+    __device__ __forceinline__ uint32_t peek(uint32_t k) const { return (uint32_t)__builtin_amdgcn_readlane((int)w, (int)(k - base)); }
+    __device__ __forceinline__ void ensure(uint32_t first, uint32_t count) { if (first + count - base > 64u) load(first); }
 };
 
-// sum of n terms (coeff id, wire id); wave-uniform control flow
-__device__ __forceinline__ fe eval_terms(const uint32_t* t, uint32_t n, const fe* coeff, const fe* W, size_t batch, size_t p) {
+// element j of v, j wave-uniform: a select chain keeps v in registers (dynamic indexing would go to scratch)
+__device__ __forceinline__ fe pick(const fe (&v)[8], uint32_t j) {
+    fe r = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = j == (uint32_t)k ? v[k].l[i] : r.l[i];
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t limb_at(const fe& v, uint32_t i) {
+    uint32_t r = v.l[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) r = i == (uint32_t)k ? v.l[k] : r;
+    return r;
+}
+
+// Linear expression [n, (cid, wid) x n] at word `at`: loads of up to 8 wires are issued back to back (one memory
+// round), then folded by a rolled loop so that the code — in particular the Montgomery product — exists once.
+// Code size matters here: every wave runs this straight-line path once, so instruction-cache misses dominate
+// if the body is unrolled (measured: 330 KB of code made a level take 170 us instead of ~20).
+__device__ __forceinline__ fe eval_expr(Window& win, uint32_t at, const fe* coeff, const fe* W, size_t batch, size_t p, uint32_t& next, int dbg) {
+    const uint32_t n = win.get(at);
+    next = at + 1 + 2 * n;
     fe acc = Fr::zero();
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t cid = uni(t[2 * k]), wid = uni(t[2 * k + 1]);
-        if (wid == WIRE_CONST) { acc = Fr::add(acc, load_fe(coeff + cid)); continue; }
-        fe w = load_fe(W + (size_t)wid * batch + p);
-        // gnark reserves coefficient ids 0..4 for 0, 1, 2, -1, -2 (checked on the host at InitAlgorithm)
-        if (cid == 1) acc = Fr::add(acc, w);
-        else if (cid == 3) acc = Fr::sub(acc, w);
-        else if (cid == 2) acc = Fr::add(acc, Fr::dbl(w));
-        else if (cid == 4) acc = Fr::sub(acc, Fr::dbl(w));
-        else if (cid != 0) acc = Fr::add(acc, Fr::mul(load_fe(coeff + cid), w));
+    for (uint32_t k0 = 0; k0 < n; k0 += 8) {
+        const uint32_t t0 = at + 1 + 2 * k0;
+        win.ensure(t0, 16);                                   // the whole chunk inside the window
+        uint32_t cidv[8], widv[8];                            // wave-uniform: scalar registers
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool live = k0 + j < n;
+            cidv[j] = live ? win.peek(t0 + 2 * j) : 0u;
+            widv[j] = live ? win.peek(t0 + 2 * j + 1) : WIRE_CONST;
+        }
+        // Wire values and coefficients: 32 loads requested back to back, branch-free (dead slots read coefficient 0, which is
+        // cached), so that no control-flow join forces an early s_waitcnt and the whole chunk costs one memory round.
+        fe v[8], cfs[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const fe* src = widv[j] == WIRE_CONST ? coeff + cidv[j] : W + (size_t)widv[j] * batch + p;
+            v[j] = load_fe(src);
+            cfs[j] = load_fe(coeff + cidv[j]);
+        }
+        if (dbg & 4) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { v[j] = Fr::one(); cfs[j] = Fr::one(); }
+        }
+        // Fold.  A lone wave issues one VALU instruction every ~9 cycles, so the per-term instruction count is what a long
+        // expression (ChaCha's 130-term add32 rows) costs: the common cases are unrolled with static register indices;
+        // only terms that really need a Montgomery product (general coefficient times a non-bit value) take the rolled path.
+        uint32_t slow = 0;
+        if (dbg & 8) { acc = Fr::add(acc, v[0]); continue; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (k0 + j < n) {
+                const uint32_t c = widv[j] == WIRE_CONST ? 1u : cidv[j];
+                // gnark reserves coefficient ids 0..4 for 0, 1, 2, -1, -2 (checked on the host at InitAlgorithm)
+                if (c == 1) acc = Fr::add(acc, v[j]);
+                else if (c == 3) acc = Fr::sub(acc, v[j]);
+                else if (c == 2) acc = Fr::add(acc, Fr::dbl(v[j]));
+                else if (c == 4) acc = Fr::sub(acc, Fr::dbl(v[j]));
+                else if (c > 4) {
+                    // Most wires of these circuits are bits: when every lane's value is 0 or 1 the product is a select.
+                    const bool is0 = Fr::is_zero(v[j]), is1 = Fr::eq(v[j], Fr::one());
+                    if (__builtin_amdgcn_ballot_w64(!(is0 || is1)) != 0) slow |= 1u << j;
+                    else acc = Fr::add(acc, is1 ? cfs[j] : Fr::zero());
+                }
+            }
+        }
+#pragma unroll 1
+        while (slow) {
+            const uint32_t j = __builtin_ctz(slow); slow &= slow - 1;
+            acc = Fr::add(acc, Fr::mul(pick(cfs, j), pick(v, j)));
+        }
     }
     return acc;
 }
 
-__global__ __launch_bounds__(64) void k_solver(SolverArgs a) {
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+// One launch per level (the kernel boundary is the inter-level barrier and makes the previous level's stores
+// visible chip-wide); grid = (proof groups of 64, ceil(ops in level / WPB)); one op per wave.
+template <bool HAS_DIV>
+__global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t p = (size_t)blockIdx.x * 64 + lane;
     const size_t batch = a.batch;
-    const uint32_t* pc = a.prog + a.first_word;
-    uint32_t fail = a.resume ? a.status[p] : 0u;
-    uint32_t op_index = 0;
-    bool first = true;
-    for (;; op_index++) {
-        const uint32_t hdr = uni(pc[0]);
-        const uint32_t op = hdr & 0xFF, len = hdr >> 8;
-        if (op == OP_END) break;
-        if (op == OP_COMMIT && !(first && a.resume)) break;      // the host finishes the commitment, then resumes here
-        first = false;
-        if (op == OP_R1C) {
-            const uint32_t loc = uni(pc[1]), nL = uni(pc[2]), nR = uni(pc[3]), nO = uni(pc[4]);
-            const uint32_t cidx = uni(pc[5]), uw = uni(pc[6]), uc = uni(pc[7]);
-            const uint32_t* t = pc + 8;
-            fe va = eval_terms(t, nL, a.coeff, a.W, batch, p);
-            fe vb = eval_terms(t + 2 * nL, nR, a.coeff, a.W, batch, p);
-            fe vc = eval_terms(t + 2 * (nL + nR), nO, a.coeff, a.W, batch, p);
-            if (loc == 0) {
-                if (!Fr::eq(Fr::mul(va, vb), vc) && !fail) fail = 1 + op_index;
-            } else {
-                fe wire;
-                if (loc == 3) { fe ab = Fr::mul(va, vb); wire = Fr::sub(ab, vc); vc = ab; }
-                else {
-                    fe known = loc == 1 ? vb : va;
-                    fe part = loc == 1 ? va : vb;
-                    if (Fr::is_zero(known)) {
-                        wire = Fr::zero();
-                        if (!Fr::eq(Fr::mul(va, vb), vc) && !fail) fail = 1 + op_index;
-                    } else {
-                        wire = Fr::sub(Fr::mul(vc, Fr::inv(known)), part);
-                        part = Fr::add(part, wire);
+    const uint32_t nlev = a.sched[0];
+    const uint32_t* lstart = a.sched + 1;
+    const uint32_t* ops = a.sched + 2 + nlev;
+    const uint32_t lev = a.first_level;
+    const uint32_t i = lstart[lev] + blockIdx.y * WPB + wave;
+    if (i >= lstart[lev + 1]) return;
+    const int dbg = a.dbg;
+    if (dbg & 1) return;
+    unsigned long long t0c = 0, t0r = 0;
+    if (dbg & 32) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    bool bad = false;
+    Window win{a.prog, 0, 0, lane};
+    const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)ops[i]);
+    win.load(at);
+    const uint32_t op = win.get(at) & 0xFF;
+    if (dbg & 2) return;
+    if (op == OP_R1C || op == OP_NBITS || op == OP_LOOKUP) {
+        // common shape: a run of linear expressions, each followed by an op-specific step
+        const uint32_t f1 = win.get(at + 1), f2 = win.get(at + 2), f3 = win.get(at + 3), f4 = win.get(at + 4);
+        const uint32_t nexpr = op == OP_R1C ? 3u : op == OP_NBITS ? 1u : f2;
+        uint32_t q = op == OP_R1C ? at + 5 : op == OP_NBITS ? at + 3 : at + 4;
+        fe va = Fr::zero(), vb = Fr::zero(), vc = Fr::zero();
+#pragma unroll 1
+        for (uint32_t e = 0; e < nexpr; e++) {
+            uint32_t next;
+            fe r = eval_expr(win, q, a.coeff, a.W, batch, p, next, dbg);
+            if (dbg & 16) { if (e == nexpr - 1) store_fe(a.A + p, r); q = next; continue; }
+            q = next;
+            if (op == OP_R1C) { if (e == 0) va = r; else if (e == 1) vb = r; else vc = r; }
+            else {
+                r = Fr::from_mont(r);
+                if (op == OP_NBITS) {                       // [hdr, out0, nOut, expr]
+                    const fe one = Fr::one(), zero = Fr::zero();
+                    for (uint32_t k = 0; k < f2; k++) {
+                        const uint32_t bit = k < 256 ? (limb_at(r, k >> 5) >> (k & 31)) & 1u : 0u;
+                        store_fe(a.W + (size_t)(f1 + k) * batch + p, bit ? one : zero);
                     }
+                } else {                                    // OP_LOOKUP [hdr, out0, nIn, table, exprs]
+                    const uint32_t hi = r.l[1] | r.l[2] | r.l[3] | r.l[4] | r.l[5] | r.l[6] | r.l[7];
+                    if (hi != 0 || r.l[0] >= 256) bad = true;
+                    const uint32_t cid = a.lookup_coeff[f3 * 256 + (r.l[0] & 255)];
+                    store_fe(a.W + (size_t)(f1 + e) * batch + p, load_fe(a.coeff + cid));
+                }
+            }
+        }
+        if (op == OP_R1C) {                                 // [hdr, loc, constraint, unk_wire, unk_coeff, L, R, O]
+            const uint32_t loc = f1, cidx = f2, uw = f3, uc = f4;
+            fe ab = Fr::mul(va, vb);
+            if (loc == 0) bad = !Fr::eq(ab, vc);
+            else {
+                fe wire;
+                if (loc == 3) { wire = Fr::sub(ab, vc); vc = ab; }
+                else {
+                    const fe known = loc == 1 ? vb : va;
+                    fe part = loc == 1 ? va : vb;
+                    if (Fr::is_zero(known)) { wire = Fr::zero(); bad = !Fr::eq(ab, vc); }   // gnark: cannot divide; the constraint must already hold
+                    else if (HAS_DIV) { wire = Fr::sub(Fr::mul(vc, Fr::inv(known)), part); part = Fr::add(part, wire); }
+                    else { wire = Fr::zero(); bad = true; }     // the host selects HAS_DIV whenever the program divides
                     if (loc == 1) va = part; else vb = part;
                 }
                 wire = Fr::mul(wire, load_fe(a.coeff_inv + uc));
@@ -80,60 +187,18 @@ __global__ __launch_bounds__(64) void k_solver(SolverArgs a) {
             store_fe(a.A + (size_t)cidx * batch + p, va);
             store_fe(a.B + (size_t)cidx * batch + p, vb);
             store_fe(a.C + (size_t)cidx * batch + p, vc);
-        } else if (op == OP_NBITS) {
-            const uint32_t o0 = uni(pc[1]), nout = uni(pc[2]), nt = uni(pc[3]);
-            fe v = Fr::from_mont(eval_terms(pc + 4, nt, a.coeff, a.W, batch, p));
-            const fe one = Fr::one(), zero = Fr::zero();
-            for (uint32_t k = 0; k < nout; k++) {
-                const uint32_t bit = k < 256 ? (v.l[k >> 5] >> (k & 31)) & 1u : 0u;
-                store_fe(a.W + (size_t)(o0 + k) * batch + p, bit ? one : zero);
-            }
-        } else if (op == OP_LOOKUP) {
-            const uint32_t o0 = uni(pc[1]), nin = uni(pc[2]), table = uni(pc[3]);
-            const uint32_t* q = pc + 4;
-            for (uint32_t k = 0; k < nin; k++) {
-                const uint32_t nt = uni(q[0]);
-                fe v = Fr::from_mont(eval_terms(q + 1, nt, a.coeff, a.W, batch, p));
-                q += 1 + 2 * nt;
-                uint32_t hi = v.l[1] | v.l[2] | v.l[3] | v.l[4] | v.l[5] | v.l[6] | v.l[7];
-                uint32_t idx = v.l[0];
-                if ((hi != 0 || idx >= 256) && !fail) { fail = 1 + op_index; }
-                idx &= 255;
-                const uint32_t cid = a.lookup_coeff[table * 256 + idx];
-                store_fe(a.W + (size_t)(o0 + k) * batch + p, load_fe(a.coeff + cid));
-            }
-        } else if (op == OP_COUNT) {
-            // out[i] = number of query rows equal to table row i.  Rows are nvars linear expressions each.
-            const uint32_t o0 = uni(pc[1]), ntab = uni(pc[2]), nvars = uni(pc[3]), nq = uni(pc[4]);
-            const uint32_t* rows = pc + 5;
-            // walk to the first query row
-            const uint32_t* qrows = rows;
-            for (uint32_t k = 0; k < ntab * nvars; k++) qrows += 1 + 2 * uni(qrows[0]);
-            const uint32_t* tr = rows;
-            for (uint32_t i = 0; i < ntab; i++) {
-                fe trow[2];
-                for (uint32_t v = 0; v < nvars && v < 2; v++) { const uint32_t nt = uni(tr[0]); trow[v] = eval_terms(tr + 1, nt, a.coeff, a.W, batch, p); tr += 1 + 2 * nt; }
-                uint32_t cnt = 0;
-                const uint32_t* qr = qrows;
-                for (uint32_t q = 0; q < nq; q++) {
-                    bool same = true;
-                    for (uint32_t v = 0; v < nvars && v < 2; v++) { const uint32_t nt = uni(qr[0]); fe qv = eval_terms(qr + 1, nt, a.coeff, a.W, batch, p); qr += 1 + 2 * nt; same = same && Fr::eq(qv, trow[v]); }
-                    cnt += same ? 1u : 0u;
-                }
-                store_fe(a.W + (size_t)(o0 + i) * batch + p, Fr::from_u32(cnt));
-            }
-        } else if (op == OP_RANDOMIZE) {
-            const uint32_t o0 = uni(pc[1]), nout = uni(pc[2]);
-            fe v = a.mask ? load_fe(a.mask + p) : Fr::zero();
-            for (uint32_t k = 0; k < nout; k++) store_fe(a.W + (size_t)(o0 + k) * batch + p, v);
-        } else if (op == OP_COMMIT) {
-            const uint32_t o0 = uni(pc[1]), nout = uni(pc[2]);
-            fe v = a.commit ? load_fe(a.commit + p) : Fr::zero();
-            for (uint32_t k = 0; k < nout; k++) store_fe(a.W + (size_t)(o0 + k) * batch + p, v);
         }
-        pc += len;
+    } else if (op == OP_RANDOMIZE || op == OP_COMMIT) {      // [hdr, out0, nOut]
+        const uint32_t o0 = win.get(at + 1), nout = win.get(at + 2);
+        const fe* src = op == OP_RANDOMIZE ? a.mask : a.commit;
+        fe v = src ? load_fe(src + p) : Fr::zero();
+        for (uint32_t k = 0; k < nout; k++) store_fe(a.W + (size_t)(o0 + k) * batch + p, v);
     }
-    a.status[p] = fail;
+    if (bad) atomicMin(a.status + p, i);     // status: 0xFFFFFFFF = satisfied, else first failing op
+    if ((dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(a.dbg_out, (unsigned long long)(t1c - t0c)); atomicAdd(a.dbg_out + 1, (unsigned long long)(t1r - t0r));
+    }
 }
 
 __global__ void k_assign_chacha(const uint8_t* inputs, fe* W, size_t batch) {
@@ -200,8 +265,13 @@ void launch_assign_aes(const uint8_t* inputs, int keylen, fe* W, size_t batch, h
 void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_rs, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, rs, W, n_wires, batch);
 }
-void launch_solver(const SolverArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_solver, dim3((unsigned)(a.batch / 64)), dim3(64), 0, s, a);
+void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
+    if (!level_width) return;
+    const dim3 grid((unsigned)(a.batch / 64), (level_width + WPB - 1) / WPB), block(64 * WPB);
+    // the division-free variant (ChaCha20-V3 never divides) carries no call to the inversion routine and so needs no
+    // scratch memory: a kernel with scratch pays a per-dispatch setup that dominated the 163 short level launches
+    if (a.has_div) hipLaunchKernelGGL(k_solver<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_solver<false>, grid, block, 0, s, a);
 }
 
 }  // namespace gsc

@@ -42,15 +42,19 @@ void launch_assign_aes(const uint8_t* inputs, int keylen, fe* W, size_t batch, h
 // rs: batch x 2 x 32 B little-endian canonical (r, s).  Fills rows nw..nw+3 of W: r, s, -r*s, 0 (Montgomery).
 void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, hipStream_t s);
 struct SolverArgs {
-    const uint32_t* prog; size_t first_word;       // start executing here, stop at OP_END or OP_COMMIT (unless resume)
+    const uint32_t* prog; const uint32_t* sched;   // instruction words; level schedule (formats.hpp SolverProgram::sched)
+    uint32_t first_level, end_level;               // the level this launch executes (end_level unused by the kernel)
     const fe* coeff; const fe* coeff_inv; const uint32_t* lookup_coeff;
     fe* W; fe* A; fe* B; fe* C; size_t batch;
-    uint32_t* status;                               // per proof: 0 ok, else 1 + op index of the first failing op
+    uint32_t* status;                               // per proof: 0xFFFFFFFF satisfied (caller initialises), else index of the first failing op
     const fe* mask;                                 // per proof value for hints.Randomize (Montgomery) or nullptr
     const fe* commit;                               // per proof commitment challenge (Montgomery) or nullptr
-    int resume;                                     // 1: first op is the OP_COMMIT to apply
+    int has_div;                                    // program contains divisions (R1C solved in L or R)
+    int dbg;                                        // timing experiments only (GSC_DBG); 0 in production
+    unsigned long long* dbg_out;                    // [2]: shader-clock ticks, 100 MHz realtime ticks (dbg & 32)
 };
-void launch_solver(const SolverArgs& a, hipStream_t s);
+// executes level a.first_level, which holds `level_width` instructions
+void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
 
 // ---- quotient polynomial (k_ntt.hip) ----
 struct NttPlan { int L; const fe* tw_fwd; const fe* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* den_inv; };

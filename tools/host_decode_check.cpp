@@ -15,8 +15,8 @@ int main(int argc, char** argv) {
         auto b = slurp(d + "/" + files[i]);
         R1csFile cs = parse_r1cs(b.data(), b.size());
         SolverProgram sp = build_solver_program(cs);
-        printf("%s.instr=%zu %s.wires=%zu %s.constraints=%zu %s.inversions=%zu %s.tables=%zu %s.words=%zu\n", names[i], cs.n_instr(), names[i], cs.n_wires(),
-               names[i], cs.n_constraints, names[i], sp.n_inversions, names[i], sp.n_tables, names[i], sp.words.size());
+        printf("%s.instr=%zu %s.wires=%zu %s.constraints=%zu %s.inversions=%zu %s.tables=%zu %s.words=%zu %s.levels=%zu %s.width=%zu %s.commit_level=%zu\n", names[i], cs.n_instr(), names[i], cs.n_wires(),
+               names[i], cs.n_constraints, names[i], sp.n_inversions, names[i], sp.n_tables, names[i], sp.words.size(), names[i], sp.n_levels, names[i], sp.max_level_width, names[i], sp.commit_level);
         if (i == 0) { try { parse_r1cs(b.data(), b.size() - 100); printf("truncated.r1cs=accepted\n"); } catch (const std::exception&) { printf("truncated.r1cs=rejected\n"); } }
     }
     auto k = slurp(d + "/pk.chacha20");
