@@ -68,7 +68,7 @@ def _cpu_worker(args):
     return time.time() - t
 
 
-def cpu_baseline(cores, per_core=4):
+def cpu_baseline(cores, per_core=24):
     """Oracle (CPU port of the same path) on `cores` host cores: independent single-threaded provers, one per core."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -94,6 +94,7 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ["GSC_DEVICE"] = str(local_rank)
     os.environ.setdefault("GSC_MAX_BATCH", str(args.batch))
+    os.environ.setdefault("GSC_WINDOW_Z", "13")       # 172 GB of Z digit tables: the bench configuration (library default is 12)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():

@@ -57,7 +57,7 @@ EngineConfig config_from_env() {
     EngineConfig c;
     c.device = env_int("GSC_DEVICE", 0);
     c.max_batch = (size_t)env_int("GSC_MAX_BATCH", 1024);
-    c.window_z = env_int("GSC_WINDOW_Z", 10);
+    c.window_z = env_int("GSC_WINDOW_Z", 12);
     c.window_w = env_int("GSC_WINDOW_W", 8);
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;

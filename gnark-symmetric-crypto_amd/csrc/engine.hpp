@@ -29,7 +29,7 @@ struct ProofResult {
 struct EngineConfig {
     int device = 0;
     size_t max_batch = 1024;     // proofs in flight per launch sequence (rounded to a multiple of 64)
-    int window_z = 10;           // digit width of the Z (quotient) tables
+    int window_z = 12;           // digit width of the Z (quotient) tables: 12 -> 94 GB, 13 -> 172 GB of HBM (bench.py uses 13)
     int window_w = 8;            // digit width of the A / B1 / B2 / K tables
 };
 EngineConfig config_from_env();
