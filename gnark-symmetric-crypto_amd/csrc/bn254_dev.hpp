@@ -248,7 +248,7 @@ struct Curve {
     DEVFN static X inf() { return X{F::zero(), F::zero(), F::zero(), F::zero()}; }
     DEVFN static bool is_inf(const X& p) { return F::is_zero(p.zz); }
     DEVFN static X from_aff(const A& a) { return X{a.x, a.y, F::one(), F::one()}; }
-    DEVNOINL static X dbl_slow(const X& p) { return dbl(p); }
+    DEVFN static X dbl_slow(const X& p) { return dbl(p); }   // rare path; kept inline: a real call forces register spills around it
     DEVFN static X dbl(const X& p) {
         if (is_inf(p)) return p;
         E U = F::dbl(p.y), V = F::sqr(U), Wv = F::mul(U, V), S = F::mul(p.x, V);
