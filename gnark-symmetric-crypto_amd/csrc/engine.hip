@@ -3,6 +3,7 @@
 #include "engine.hpp"
 #include "formats.hpp"
 #include "kernels.hpp"
+#include "host_ciphers.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -57,11 +58,13 @@ EngineConfig config_from_env() {
     EngineConfig c;
     c.device = env_int("GSC_DEVICE", 0);
     c.max_batch = (size_t)env_int("GSC_MAX_BATCH", 1024);
-    c.window_z = env_int("GSC_WINDOW_Z", 12);
-    c.window_w = env_int("GSC_WINDOW_W", 8);
+    c.window_z = env_int("GSC_WINDOW_Z", 0);
+    c.window_w = env_int("GSC_WINDOW_W", 0);
+    c.z_table_gb = env_int("GSC_Z_TABLE_GB", 48);
+    c.w_table_gb = env_int("GSC_W_TABLE_GB", 24);
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
-    if (c.window_z < 2 || c.window_z > 16 || c.window_w < 2 || c.window_w > 16) throw std::runtime_error("GSC_WINDOW_* must be in [2,16]");
+    if ((c.window_z && (c.window_z < 2 || c.window_z > 16)) || (c.window_w && (c.window_w < 2 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [2,16]");
     return c;
 }
 
@@ -78,14 +81,15 @@ class AlgorithmImpl {
 
     // program
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
-    uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; int has_div = 0;
+    uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; int has_div = 0;
     // NTT
     DevBuf<fe> tw_fwd, tw_inv, scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
     // MSM sets
-    MsmSet<G1Aff> mA, mB1, mK, mZ; MsmSet<G2Aff> mB2;
+    MsmSet<G1Aff> mA, mB1, mK, mZ, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
     // batch buffers
     size_t cap = 0;
-    DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags; DevBuf<uint32_t> d_status; DevBuf<unsigned long long> d_dbg;
+    DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts, d_h48; DevBuf<uint32_t> d_status; DevBuf<unsigned long long> d_dbg;
+    DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
     DevBuf<fe> d_W, d_A, d_B, d_C;
     DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
 
@@ -112,6 +116,7 @@ class AlgorithmImpl {
         SolverProgram sp = build_solver_program(cs);
         n_levels = (uint32_t)sp.n_levels; commit_level = (uint32_t)sp.commit_level; has_div = sp.n_inversions ? 1 : 0;
         level_width.resize(n_levels); for (uint32_t l = 0; l < n_levels; l++) level_width[l] = sp.sched[2 + l] - sp.sched[1 + l];
+        level_kind = sp.level_kind;
         prog.alloc(sp.words.size()); prog.upload(sp.words.data(), sp.words.size(), stream);
         sched.alloc(sp.sched.size()); sched.upload(sp.sched.data(), sp.sched.size(), stream);
         lookup_coeff.alloc(sp.lookup_coeff.size() ? sp.lookup_coeff.size() : 1);
@@ -119,6 +124,15 @@ class AlgorithmImpl {
         coeff.alloc(cs.n_coeff()); coeff_inv.alloc(cs.n_coeff());
         HIP_CHECK(hipMemcpyAsync(coeff.p, cs.coeff_limbs.data(), cs.coeff_limbs.size() * 4, hipMemcpyHostToDevice, stream));
         launch_fr_inverse(coeff.p, coeff_inv.p, cs.n_coeff(), stream);
+        if (!sp.count_ops.empty()) {      // lookup histograms rely on table row i carrying index i: verify once, on the device
+            DevBuf<uint32_t> d_ops(sp.count_ops.size()), d_flag(1); uint32_t flag = 0;
+            d_ops.upload(sp.count_ops.data(), sp.count_ops.size(), stream);
+            HIP_CHECK(hipMemsetAsync(d_flag.p, 0, 4, stream));
+            launch_check_count_tables(prog.p, coeff.p, d_ops.p, (uint32_t)sp.count_ops.size(), d_flag.p, stream);
+            HIP_CHECK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (flag) throw std::runtime_error("r1cs: unsupported lookup table (index column is not 0..n-1)");
+        }
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
@@ -169,7 +183,6 @@ class AlgorithmImpl {
         domain_n = key.domain_n; L = 0; while (((size_t)1 << L) < domain_n) L++;
         if (domain_n < n_constraints || L < 4 || L > 24) throw std::runtime_error("pk: domain too small for the constraint system");
         if (cs.has_commitment != key.has_commitment_key) throw std::runtime_error("pk: commitment keys do not match the r1cs");
-        if (cs.has_commitment) throw std::runtime_error("commitment (AES-V2) circuits: device path not wired yet");
         // NTT constants
         {
             uint8_t be[5 * 32];
@@ -196,6 +209,14 @@ class AlgorithmImpl {
         rowsB.push_back(ROW_ONE); rowsB.push_back(ROW_S); rowsB2.push_back(ROW_ONE); rowsB2.push_back(ROW_S);
         rowsK.push_back(ROW_NRS);
         std::vector<uint32_t> rowsZ(domain_n - 1); for (size_t i = 0; i < rowsZ.size(); i++) rowsZ[i] = (uint32_t)i;
+        // Digit widths: explicit (GSC_WINDOW_Z / GSC_WINDOW_W) or the largest that keeps the tables inside the per-algorithm
+        // HBM budget (defaults leave room for all three algorithms of the reference on one 288 GB device).
+        auto table_bytes_for = [](size_t nbases, int c, size_t entry) { return (double)nbases * ((254 + c - 1) / c) * (double)((size_t)1 << (c - 1)) * (double)entry; };
+        if (!cfg.window_z) { cfg.window_z = 4; for (int c = 13; c >= 4; c--) if (table_bytes_for(rowsZ.size(), c, 64) <= cfg.z_table_gb * 1e9) { cfg.window_z = c; break; } }
+        if (!cfg.window_w) {
+            const size_t g1n = rowsA.size() + rowsB.size() + rowsK.size() + 2 * cs.commit_private.size(), g2n = rowsB2.size();
+            cfg.window_w = 3; for (int c = 8; c >= 3; c--) if (table_bytes_for(g1n, c, 64) + table_bytes_for(g2n, c, 128) <= cfg.w_table_gb * 1e9) { cfg.window_w = c; break; }
+        }
         auto dec1 = [this](const std::vector<uint8_t>& raw, G1Aff* out) { return decompress_g1(raw, out); };
         auto dec2 = [this](const std::vector<uint8_t>& raw, G2Aff* out) { return decompress_g2(raw, out); };
         // tables are built in chunks of rows so that the projective scratch stays below ~4 GiB
@@ -218,16 +239,23 @@ class AlgorithmImpl {
         build_set(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, bld1);
         build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1);
         build_set(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, bld2);
+        if (cs.has_commitment) {
+            if (cs.n_public_committed) throw std::runtime_error("r1cs: public committed wires are not supported");
+            if (key.ped_basis.size() != cs.commit_private.size() * 32) throw std::runtime_error("pk: commitment basis size does not match the r1cs");
+            build_set(mPed, key.ped_basis, 32, cs.commit_private, cfg.window_w, "commitment basis", dec1, bld1);
+            build_set(mPedSigma, key.ped_basis_sigma, 32, cs.commit_private, cfg.window_w, "commitment basis (sigma)", dec1, bld1);
+        }
     }
 
     void alloc_batch(size_t B) {
         cap = B;
         d_dbg.alloc(2); d_inputs.alloc(176 * B); d_rs.alloc(64 * B); d_out.alloc(256 * B); d_flags.alloc((B + 3) / 4 * 4); d_status.alloc(B);
         d_W.alloc((n_wires + 4) * B); d_A.alloc(domain_n * B); d_B.alloc(domain_n * B); d_C.alloc(domain_n * B);
-        size_t s1 = mA.nslices; for (size_t v : {mB1.nslices, mK.nslices, mZ.nslices}) if (v > s1) s1 = v;
+        size_t s1 = mA.nslices; for (size_t v : {mB1.nslices, mK.nslices, mZ.nslices, mPed.nslices}) if (v > s1) s1 = v;
         d_part1a.alloc(s1 * B); d_part1b.alloc((s1 + 63) / 64 * B);
         d_part2a.alloc(mB2.nslices * B); d_part2b.alloc((mB2.nslices + 63) / 64 * B);
         d_sumA.alloc(B); d_sumB1.alloc(B); d_sumK.alloc(B); d_sumZ.alloc(B); d_sumB2.alloc(B); d_tmp.alloc(2 * B);
+        if (has_commitment) { d_mask_in.alloc(32 * B); d_mask.alloc(B); d_commit.alloc(B); d_cpts.alloc(128 * B); d_h48.alloc(48 * B); d_sumD.alloc(B); d_sumPok.alloc(B); }
     }
 
     void run_msm_g1(const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
@@ -282,11 +310,38 @@ class AlgorithmImpl {
         // 1. witness
         if (cipher == CHACHA20) launch_assign_chacha(d_inputs.p, d_W.p, B, stream);
         else launch_assign_aes(d_inputs.p, cipher == AES_128 ? 16 : 32, d_W.p, B, stream);
-        launch_prep_rs(d_rs.p, d_W.p, n_wires, B, stream);
+        if (has_commitment) {
+            std::vector<uint8_t> h_mask(32 * B);
+            for (size_t i = 0; i < B; i++) memcpy(h_mask.data() + 32 * i, reqs[i < n ? i : n - 1].mask, 32);
+            d_mask_in.upload(h_mask.data(), h_mask.size(), stream);
+        }
+        launch_prep_rs(d_rs.p, d_W.p, n_wires, B, has_commitment ? d_mask_in.p : nullptr, d_mask.p, stream);
         HIP_CHECK(hipMemsetAsync(d_status.p, 0xFF, B * 4, stream));
-        SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p, nullptr, nullptr, has_div, env_int("GSC_DBG", 0), d_dbg.p};
+        SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p,
+                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, env_int("GSC_DBG", 0), d_dbg.p};
         if (sa.dbg & 32) HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 16, stream));
-        for (uint32_t l = 0; l < n_levels; l++) { sa.first_level = l; launch_solver_level(sa, level_width[l], stream); }
+        auto run_levels = [&](uint32_t from, uint32_t to) {
+            for (uint32_t l = from; l < to; l++) {
+                sa.first_level = l;
+                if (level_kind[l]) launch_solver_count_level(sa, level_width[l], stream); else launch_solver_level(sa, level_width[l], stream);
+            }
+        };
+        std::vector<uint8_t> h_cpts;
+        if (has_commitment) {
+            // Groth16 commitment (gnark "BSB22"): solve up to the commitment hint, D = sum w_j * Basis_j over the
+            // committed wires (same table MSM as everything else), challenge = hash_to_field(D uncompressed), resume.
+            run_levels(0, commit_level);
+            run_msm_g1(mPed, d_W.p, 1, B, d_sumD.p);
+            launch_points_to_affine_be(d_sumD.p, B, d_cpts.p, d_flags.p, 8, stream);
+            h_cpts.resize(128 * B);
+            HIP_CHECK(hipMemcpyAsync(h_cpts.data(), d_cpts.p, 64 * B, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            std::vector<uint8_t> h48(48 * B);
+            for (size_t i = 0; i < B; i++) expand_message_xmd_sha256(h_cpts.data() + 64 * i, 64, "bsb22-commitment", h48.data() + 48 * i, 48);
+            d_h48.upload(h48.data(), h48.size(), stream);
+            launch_challenge_from_hash(d_h48.p, d_commit.p, B, stream);
+            run_levels(commit_level, n_levels);
+        } else run_levels(0, n_levels);
         HIP_CHECK(hipEventRecord(ev[1], stream));
         if (sa.dbg & 32) { unsigned long long h[2]; HIP_CHECK(hipMemcpyAsync(h, d_dbg.p, 16, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream));
             printf("solver wave0: %llu shader cycles, %llu x10ns -> %.0f MHz, %.1f us busy\n", h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[1] / 100.0); }
@@ -306,6 +361,10 @@ class AlgorithmImpl {
         run_msm_g2(mB2, d_W.p, 1, B, d_sumB2.p);
         run_msm_g1(mK, d_W.p, 1, B, d_sumK.p);
         run_msm_g1(mZ, d_A.p, 0, B, d_sumZ.p, true);
+        if (has_commitment) {      // proof of knowledge of the commitment: same scalars over sigma * Basis
+            run_msm_g1(mPedSigma, d_W.p, 1, B, d_sumPok.p);
+            launch_points_to_affine_be(d_sumPok.p, B, d_cpts.p + 64 * B, d_flags.p, 16, stream);
+        }
         HIP_CHECK(hipEventRecord(ev[3], stream));
         // 4. assembly
         launch_finalize(d_sumA.p, d_sumB1.p, d_sumB2.p, d_sumK.p, d_sumZ.p, d_rs.p, B, d_out.p, d_flags.p, d_tmp.p, stream);
@@ -314,14 +373,16 @@ class AlgorithmImpl {
         HIP_CHECK(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(h_flags.data(), d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, B * 4, hipMemcpyDeviceToHost, stream));
+        if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data() + 64 * B, d_cpts.p + 64 * B, 64 * B, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]); stage_ms[k] = ms; }
         (void)hipEventElapsedTime(&msm_z_kernel_ms, ev[5], ev[6]); last_batch = B;
-        for (size_t i = 0; i < n; i++) serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], results[i]);
+        for (size_t i = 0; i < n; i++)
+            serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts.data() + 64 * i : nullptr, has_commitment ? h_cpts.data() + 64 * B + 64 * i : nullptr, results[i]);
     }
 
     // gnark proof.WriteTo: Ar | Bs | Krs compressed, u32be nbCommitments, commitments, CommitmentPok
-    void serialize(const uint8_t* o, uint8_t flags, uint32_t status, ProofResult& res) const {
+    void serialize(const uint8_t* o, uint8_t flags, uint32_t status, const uint8_t* commitment_xy, const uint8_t* pok_xy, ProofResult& res) const {
         res.proof_len = 0; res.status = 0;
         if (status != 0xFFFFFFFFu) { res.status = 1; return; }
         if (flags) { res.status = 2; return; }
@@ -339,9 +400,16 @@ class AlgorithmImpl {
             p[32] |= large ? 0xC0 : 0x80;
         }
         g1(o + 192, p + 96);
-        p[128] = p[129] = p[130] = p[131] = 0;          // no commitments (ChaCha20-V3)
-        memset(p + 132, 0, 32); p[132] = 0x40;          // CommitmentPok = point at infinity
-        res.proof_len = 164;
+        if (!commitment_xy) {
+            p[128] = p[129] = p[130] = p[131] = 0;          // no commitments (ChaCha20-V3)
+            memset(p + 132, 0, 32); p[132] = 0x40;          // CommitmentPok = point at infinity
+            res.proof_len = 164;
+        } else {                                            // one commitment + its proof of knowledge (AES-V2)
+            p[128] = p[129] = p[130] = 0; p[131] = 1;
+            auto g1be = [&](const uint8_t* xy, uint8_t* dst) { memcpy(dst, xy, 32); dst[0] |= be_greater(xy + 32, kHalfP) ? 0xC0 : 0x80; };
+            g1be(commitment_xy, p + 132); g1be(pok_xy, p + 164);
+            res.proof_len = 196;
+        }
     }
 };
 

@@ -29,8 +29,9 @@ struct ProofResult {
 struct EngineConfig {
     int device = 0;
     size_t max_batch = 1024;     // proofs in flight per launch sequence (rounded to a multiple of 64)
-    int window_z = 12;           // digit width of the Z (quotient) tables: 12 -> 94 GB, 13 -> 172 GB of HBM (bench.py uses 13)
-    int window_w = 8;            // digit width of the A / B1 / B2 / K tables
+    int window_z = 0;            // digit width of the Z (quotient) tables; 0 = largest that fits z_table_gb (ChaCha: 12 -> 94 GB, 13 -> 172 GB; bench.py uses 13)
+    int window_w = 0;            // digit width of the A / B1 / B2 / K / commitment tables; 0 = largest <= 8 that fits w_table_gb
+    int z_table_gb = 48, w_table_gb = 24;   // per-algorithm HBM budgets used when the widths are not given
 };
 EngineConfig config_from_env();
 

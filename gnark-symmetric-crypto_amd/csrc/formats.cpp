@@ -267,7 +267,7 @@ SolverProgram build_solver_program(const R1csFile& cs) {
     }
     auto& W = sp.words;
     std::vector<uint32_t> wire_level(nw, 0);          // level at which a wire's value becomes available (inputs: 0)
-    std::vector<uint32_t> op_level, op_offset; size_t commit_op = (size_t)-1;
+    std::vector<uint32_t> op_level, op_offset, count_ops; size_t commit_op = (size_t)-1;
     uint32_t cur_level = 0;                            // max wire_level over the wires the current op reads
     auto check_wire = [&](uint32_t wid) {
         if (wid == WIRE_CONST) return;
@@ -331,28 +331,28 @@ SolverProgram build_solver_program(const R1csFile& cs) {
                 W.insert(W.end(), {0u, o0, nout}); copy_linexp(in, p);
                 W[hdr_at] = OP_NBITS;
             } else if (hid == HINT_COUNT) {
-                // inputs: [nTable, nVars, table rows..., query rows...]; the two sizes are constant expressions
-                auto const_small = [&](const uint32_t* q, uint32_t& v) {
-                    // value = coefficient of a constant term; the reference circuits use coefficient ids whose value
-                    // is a small integer, resolved on the device; here only the shape is needed, so derive it from counts.
-                    (void)q; (void)v;
-                };
-                (void)const_small;
+                // inputs: [nTable, nVars, table rows..., query rows...] (std/internal/logderivarg.countHint).  Supported shape —
+                // the one gnark's logderivlookup emits: rows are (index, value) pairs, every table row is a pair of constant
+                // single-term expressions, and (checked on the device at InitAlgorithm) the index of table row i is i.
                 if (nin < 2) throw std::runtime_error("solver: countHint inputs");
-                // Shape: nTable = nout; nVars from (nin - 2) and table size: (nin-2) = (nTable + nQueries) * nVars.
-                // gnark's logderivlookup always uses rows of (index, value): nVars = 2.
                 const uint32_t nvars = 2;
                 if ((nin - 2) % nvars || (nin - 2) / nvars < nout) throw std::runtime_error("solver: countHint shape");
+                if (nout > 256) throw std::runtime_error("solver: countHint table larger than 256 rows");
                 const uint32_t nq = (nin - 2) / nvars - nout;
                 W.insert(W.end(), {0u, o0, nout, nvars, nq});
-                const uint32_t* q = in; q += linexp_words(q); q += linexp_words(q);    // skip the two size inputs
-                for (uint32_t k = 2; k < nin; k++) q += copy_linexp(q, p);
+                const uint32_t* q = in;
+                for (int k = 0; k < 2; k++) { if (q[0] != 1 || q[2] != WIRE_CONST) throw std::runtime_error("solver: countHint sizes must be constants"); q += linexp_words(q); }
+                for (uint32_t k = 0; k < nout * nvars; k++) {
+                    if (q[0] != 1 || q[2] != WIRE_CONST) throw std::runtime_error("solver: countHint table rows must be constants");
+                    q += copy_linexp(q, p);
+                }
+                for (uint32_t k = 0; k < nq * nvars; k++) q += copy_linexp(q, p);
                 W[hdr_at] = OP_COUNT;
+                count_ops.push_back((uint32_t)hdr_at);
             } else if (hid == HINT_RANDOMIZE) {
                 W.insert(W.end(), {0u, o0, nout}); W[hdr_at] = OP_RANDOMIZE;
             } else if (hid == HINT_BSB22) {
                 if (!cs.has_commitment || nout != 1 || o0 != cs.commit_wire) throw std::runtime_error("solver: unexpected commitment hint");
-                for (uint32_t k = 0; k < nin; k++) { const uint32_t* q = in; (void)q; }
                 W.insert(W.end(), {0u, o0, nout}); W[hdr_at] = OP_COMMIT;
                 for (uint32_t w : cs.commit_private) check_wire(w);          // the commitment reads every committed wire
                 commit_op = op_offset.size();
@@ -382,14 +382,20 @@ SolverProgram build_solver_program(const R1csFile& cs) {
     W.insert(W.end(), 64, 0u);
     // level schedule (counting sort by level; the commitment op gets a level of its own)
     uint32_t nlev = 0; for (uint32_t l : op_level) if (l + 1 > nlev) nlev = l + 1;
-    std::vector<std::vector<uint32_t>> by_level(nlev);
-    for (size_t i = 0; i < op_level.size(); i++) if (i != commit_op) by_level[op_level[i]].push_back(op_offset[i]);
+    std::vector<std::vector<uint32_t>> by_level(nlev), count_by_level(nlev);
+    {
+        std::vector<uint8_t> is_count(W.size(), 0);
+        for (uint32_t o : count_ops) is_count[o] = 1;
+        for (size_t i = 0; i < op_level.size(); i++) if (i != commit_op) (is_count[op_offset[i]] ? count_by_level : by_level)[op_level[i]].push_back(op_offset[i]);
+    }
     std::vector<std::vector<uint32_t>> levels;
     sp.commit_level = (size_t)-1;
     for (uint32_t l = 0; l < nlev; l++) {
-        if (!by_level[l].empty()) levels.push_back(by_level[l]);
-        if (commit_op != (size_t)-1 && op_level[commit_op] == l) { sp.commit_level = levels.size(); levels.push_back({op_offset[commit_op]}); }
+        if (!by_level[l].empty()) { levels.push_back(by_level[l]); sp.level_kind.push_back(0); }
+        if (!count_by_level[l].empty()) { levels.push_back(count_by_level[l]); sp.level_kind.push_back(1); }     // histogram ops: their own kernel
+        if (commit_op != (size_t)-1 && op_level[commit_op] == l) { sp.commit_level = levels.size(); levels.push_back({op_offset[commit_op]}); sp.level_kind.push_back(0); }
     }
+    sp.count_ops = count_ops;
     sp.n_levels = levels.size();
     if (sp.commit_level == (size_t)-1) sp.commit_level = sp.n_levels;
     sp.sched.push_back((uint32_t)sp.n_levels);

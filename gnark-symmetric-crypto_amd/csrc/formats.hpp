@@ -64,7 +64,7 @@ enum SolverOp : uint32_t {
     OP_R1C = 1,       // [hdr, loc, constraint, unk_wire, unk_coeff, L, R, O]   loc 0 none,1 L,2 R,3 O; L/R/O = linear expressions
                       //   (n, then n x (cid, wid)) without the term of the wire being solved
     OP_NBITS = 2,     // [hdr, out0, nOut, linear expression]
-    OP_COUNT = 3,     // [hdr, out0, nOut(=nTable), nVars, nQueries, then (nTable+nQueries)*nVars linear expressions: n, terms...]
+    OP_COUNT = 3,     // [hdr, out0, nTable, nVars(=2), nQueries, nTable x {[1,cid_index,CONST],[1,cid_value,CONST]}, nQueries x {expr, expr}]
     OP_LOOKUP = 4,    // [hdr, out0, nIn, table_id, then nIn linear expressions]
     OP_RANDOMIZE = 5, // [hdr, out0, nOut]
     OP_COMMIT = 6,    // [hdr, out0, nOut]   value supplied by the host (commitment challenge) per proof
@@ -79,6 +79,8 @@ struct SolverProgram {
     // When the circuit has a commitment, its OP_COMMIT sits alone in level `commit_level`; the host runs levels
     // [0, commit_level), computes the commitment, then runs [commit_level, n_levels).  Otherwise commit_level == n_levels.
     std::vector<uint32_t> sched;
+    std::vector<uint8_t> level_kind;         // per level: 0 = generic ops (k_solver), 1 = OP_COUNT histogram ops (k_solver_count)
+    std::vector<uint32_t> count_ops;         // word offsets of the OP_COUNT ops (checked on the device at init)
     size_t n_levels = 0, commit_level = 0, max_level_width = 0;
     size_t n_ops = 0, n_inversions = 0;
 };

@@ -180,6 +180,31 @@ __global__ __launch_bounds__(64) void k_fin_combine(const G2Xyzz* sumB2, const G
     if (fl) atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), fl << (8 * (p & 3)));
 }
 
+__global__ void k_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= batch) return;
+    Xyzz<Fp> v = reinterpret_cast<const Xyzz<Fp>*>(points)[p];
+    uint8_t* o = out + 64 * p;
+    if (G1::is_inf(v)) { for (int i = 0; i < 64; i++) o[i] = 0; atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), bit << (8 * (p & 3))); return; }
+    Aff<Fp> A = G1::to_aff(v);
+    fe x = Fp::from_mont(A.x), y = Fp::from_mont(A.y);
+    for (int i = 0; i < 8; i++) {
+        const uint32_t xw = x.l[7 - i], yw = y.l[7 - i];
+        o[4 * i] = (uint8_t)(xw >> 24); o[4 * i + 1] = (uint8_t)(xw >> 16); o[4 * i + 2] = (uint8_t)(xw >> 8); o[4 * i + 3] = (uint8_t)xw;
+        o[32 + 4 * i] = (uint8_t)(yw >> 24); o[32 + 4 * i + 1] = (uint8_t)(yw >> 16); o[32 + 4 * i + 2] = (uint8_t)(yw >> 8); o[32 + 4 * i + 3] = (uint8_t)yw;
+    }
+}
+// 384-bit big-endian integer mod r by Horner over bytes (gnark-crypto fr.Hash reduces the 48 xmd bytes the same way)
+__global__ void k_challenge_from_hash(const uint8_t* h48, fe* commit, size_t batch) {
+    const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (p >= batch) return;
+    const uint8_t* h = h48 + 48 * p;
+    fe acc = Fr::zero();
+    const fe b256 = Fr::from_u32(256);
+    for (int i = 0; i < 48; i++) acc = Fr::add(Fr::mul(acc, b256), Fr::from_u32(h[i]));
+    store_fe(commit + p, acc);
+}
+
 }  // namespace
 
 void launch_msm_g1(const MsmArgs& a, hipStream_t s) {
@@ -195,6 +220,12 @@ void launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G
 void launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s) {
     hipLaunchKernelGGL(k_msm_reduce<Fp2>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
                        reinterpret_cast<const Xyzz<Fp2>*>(partial), nslices, batch, reinterpret_cast<Xyzz<Fp2>*>(out));
+}
+void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s) {
+    hipLaunchKernelGGL(k_points_to_affine_be, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, points, batch, out, flags, bit);
+}
+void launch_challenge_from_hash(const uint8_t* h48, fe* commit, size_t batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_challenge_from_hash, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, h48, commit, batch);
 }
 void launch_finalize(const G1Xyzz* sumA, const G1Xyzz* sumB1, const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ,
                      const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {

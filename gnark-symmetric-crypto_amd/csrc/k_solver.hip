@@ -201,6 +201,62 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
     }
 }
 
+// OP_COUNT (logderivarg.countHint): out[i] = number of query rows equal to table row i.  One wave per (64 proofs, op); the
+// 256 x 64-lane histogram lives in LDS (32 KiB).  Table rows are constants (index i, value T[i]) — shape checked on the host,
+// index column checked by k_check_count_tables at InitAlgorithm — so a query is matched by reading row `index` directly.
+__global__ __launch_bounds__(64) void k_solver_count(SolverArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_cnt[];     // [row][lane]
+    const uint32_t lane = threadIdx.x;
+    const size_t p = (size_t)blockIdx.x * 64 + lane;
+    const size_t batch = a.batch;
+    const uint32_t nlev = a.sched[0];
+    const uint32_t* lstart = a.sched + 1;
+    const uint32_t* ops = a.sched + 2 + nlev;
+    const uint32_t i = lstart[a.first_level] + blockIdx.y;
+    if (i >= lstart[a.first_level + 1]) return;
+    Window win{a.prog, 0, 0, lane};
+    const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)ops[i]);
+    win.load(at);
+    const uint32_t o0 = win.get(at + 1), ntab = win.get(at + 2), nq = win.get(at + 4);
+    for (uint32_t r = 0; r < ntab; r++) s_cnt[r * 64 + lane] = 0;
+    const uint32_t rows_base = at + 5;
+    uint32_t q = rows_base + 6 * ntab;
+    bool bad = false;
+#pragma unroll 1
+    for (uint32_t k = 0; k < nq; k++) {
+        uint32_t next;
+        fe x0 = eval_expr(win, q, a.coeff, a.W, batch, p, next, 0); q = next;
+        fe x1 = eval_expr(win, q, a.coeff, a.W, batch, p, next, 0); q = next;
+        const fe c0 = Fr::from_mont(x0);
+        const uint32_t hi = c0.l[1] | c0.l[2] | c0.l[3] | c0.l[4] | c0.l[5] | c0.l[6] | c0.l[7];
+        const bool in_range = hi == 0 && c0.l[0] < ntab;
+        const uint32_t idx = in_range ? c0.l[0] : 0u;
+        const uint32_t cidv = a.prog[rows_base + 6 * idx + 4];          // value column of table row idx
+        const fe tv = load_fe(a.coeff + cidv);
+        if (in_range && Fr::eq(x1, tv)) s_cnt[idx * 64 + lane] += 1;
+        else bad = true;                                                  // gnark: "query not in table"
+    }
+#pragma unroll 1
+    for (uint32_t r = 0; r < ntab; r++) {
+        const uint32_t c = s_cnt[r * 64 + lane];
+        fe v = Fr::zero();
+        if (__builtin_amdgcn_ballot_w64(c != 0) != 0) v = Fr::from_u32(c);
+        store_fe(a.W + (size_t)(o0 + r) * batch + p, v);
+    }
+    if (bad) atomicMin(a.status + p, i);
+}
+
+// InitAlgorithm-time check for k_solver_count: the index constant of table row r must be r.
+__global__ void k_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t op = t >> 8, row = t & 255;
+    if (op >= nops) return;
+    const uint32_t at = count_ops[op];
+    if (row >= prog[at + 2]) return;
+    const uint32_t cid = prog[at + 5 + 6 * row + 1];
+    if (!Fr::eq(load_fe(coeff + cid), Fr::from_u32(row))) atomicOr(flag, 1u);
+}
+
 __global__ void k_assign_chacha(const uint8_t* inputs, fe* W, size_t batch) {
     // 44 words per proof: Counter, Nonce[3] (LE), In[16] (BE), Out[16] (BE) public; Key[8] (LE) secret
     size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -239,7 +295,7 @@ __global__ void k_assign_aes(const uint8_t* inputs, int keylen, fe* W, size_t ba
     store_fe(W + (size_t)(1 + i) * batch + p, Fr::from_u32(v));
 }
 
-__global__ void k_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch) {
+__global__ void k_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, const uint8_t* mask_in, fe* mask_out) {
     size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= batch) return;
     const uint32_t* q = reinterpret_cast<const uint32_t*>(rs + 64 * p);
@@ -250,6 +306,11 @@ __global__ void k_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch
     store_fe(W + (n_wires + 1) * batch + p, s);
     store_fe(W + (n_wires + 2) * batch + p, Fr::neg(Fr::mul(r, s)));
     store_fe(W + (n_wires + 3) * batch + p, Fr::zero());
+    if (mask_in) {
+        const uint32_t* mq = reinterpret_cast<const uint32_t*>(mask_in + 32 * p);
+        fe m; for (int i = 0; i < 8; i++) m.l[i] = mq[i];
+        store_fe(mask_out + p, Fr::to_mont(m));
+    }
 }
 
 }  // namespace
@@ -262,8 +323,16 @@ void launch_assign_aes(const uint8_t* inputs, int keylen, fe* W, size_t batch, h
     size_t n = (size_t)(142 + keylen) * batch;
     hipLaunchKernelGGL(k_assign_aes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, inputs, keylen, W, batch);
 }
-void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_prep_rs, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, rs, W, n_wires, batch);
+void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, const uint8_t* mask_in, fe* mask_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_prep_rs, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, rs, W, n_wires, batch, mask_in, mask_out);
+}
+void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
+    if (!level_width) return;
+    hipLaunchKernelGGL(k_solver_count, dim3((unsigned)(a.batch / 64), level_width), dim3(64), 256 * 64 * sizeof(uint16_t), s, a);
+}
+void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s) {
+    if (!nops) return;
+    hipLaunchKernelGGL(k_check_count_tables, dim3(nops), dim3(256), 0, s, prog, coeff, count_ops, nops, flag);
 }
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
     if (!level_width) return;

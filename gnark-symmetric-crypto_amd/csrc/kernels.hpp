@@ -40,7 +40,8 @@ void launch_assign_chacha(const uint8_t* inputs, fe* W, size_t batch, hipStream_
 // AES records: {key[32] (zero padded), nonce[12], counter u32 LE, pt[64], ct[64]}; keylen 16 or 32
 void launch_assign_aes(const uint8_t* inputs, int keylen, fe* W, size_t batch, hipStream_t s);
 // rs: batch x 2 x 32 B little-endian canonical (r, s).  Fills rows nw..nw+3 of W: r, s, -r*s, 0 (Montgomery).
-void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, hipStream_t s);
+// mask_in (optional): batch x 32 B little-endian canonical value for hints.Randomize -> mask_out[proof] (Montgomery)
+void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, const uint8_t* mask_in, fe* mask_out, hipStream_t s);
 struct SolverArgs {
     const uint32_t* prog; const uint32_t* sched;   // instruction words; level schedule (formats.hpp SolverProgram::sched)
     uint32_t first_level, end_level;               // the level this launch executes (end_level unused by the kernel)
@@ -55,6 +56,10 @@ struct SolverArgs {
 };
 // executes level a.first_level, which holds `level_width` instructions
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
+// same for a level made of OP_COUNT ops (LDS histogram kernel)
+void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
+// *flag |= 1 if some OP_COUNT table's index column is not 0,1,2,... (InitAlgorithm-time validation)
+void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s);
 
 // ---- quotient polynomial (k_ntt.hip) ----
 struct NttPlan { int L; const fe* tw_fwd; const fe* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* den_inv; };
@@ -77,6 +82,12 @@ void launch_msm_g2(const MsmArgs& a, hipStream_t s);
 // out[proof] = sum_slices partial[slice][proof]
 void launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
 void launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
+// Commitment helpers (AES-V2).  points: batch XYZZ sums -> out: batch x 64 B big-endian canonical X|Y
+// (gnark's uncompressed G1 encoding, the prefix of the commitment hash); flags[proof] |= bit if the point is infinity.
+void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s);
+// h48: batch x 48 bytes (big-endian integers from expand_message_xmd) -> commit[proof] = value mod r, Montgomery form
+void launch_challenge_from_hash(const uint8_t* h48, fe* commit, size_t batch, hipStream_t s);
+
 // Proof assembly: inputs are the completed sums
 //   sumA = alpha + sum A + r*delta, sumB1 = beta + sum B + s*delta, sumB2 (G2), sumK = sum K - rs*delta, sumZ.
 // rs: batch x 64 B (r, s little-endian canonical).  out: batch x 256 B = Ar.x Ar.y | Bs.x.a0 Bs.x.a1 Bs.y.a0 Bs.y.a1 | Krs.x Krs.y,

@@ -126,6 +126,11 @@ EXPORT int orc_verify(const void *vkp, int cipher, const uint8_t *proof, size_t 
     }
     return groth16_verify(vk, proof, proof_len, pub, np);
 }
+/* Setup with a seed; returns malloc'd key files (free with orc_free) */
+EXPORT int orc_setup(const void *csp, const uint8_t *seed32, uint8_t **pk, size_t *pk_len, uint8_t **vk, size_t *vk_len) {
+    return groth16_setup((const r1cs_t *)csp, seed32, pk, pk_len, vk, vk_len);
+}
+EXPORT void orc_free(void *p) { free(p); }
 /* self-tests of the pairing: bilinearity on the generators */
 EXPORT int orc_pairing_selftest(void) {
     bn254_init();

@@ -24,6 +24,8 @@ void hash_to_fr(fe *out, const uint8_t *msg, size_t len, const char *dst);
 int groth16_prove(const r1cs_t *cs, const pk_t *pk, const fe *witness, const fe *r, const fe *s, const fe *mask,
                   uint8_t *proof_out, size_t *proof_len, prove_dump_t *dump);
 int groth16_verify(const vk_t *vk, const uint8_t *proof, size_t proof_len, const fe *pub, size_t n_pub);
+/* test keys in gnark layout from a seed; caller frees *pk_out / *vk_out */
+int groth16_setup(const r1cs_t *cs, const uint8_t seed[32], uint8_t **pk_out, size_t *pk_len, uint8_t **vk_out, size_t *vk_len);
 void assign_chacha(const uint8_t key[32], const uint8_t nonce[12], uint32_t counter, const uint8_t pt[64], uint8_t ct[64], fe *wit);
 void assign_aes(const uint8_t *key, int keylen, const uint8_t nonce[12], uint32_t counter, const uint8_t pt[64], uint8_t ct[64], fe *wit);
 #endif

@@ -47,6 +47,9 @@ def lib():
         L.orc_solve.restype = C.c_long
         L.orc_solve.argtypes = [vp, i32, u8p, u8p, u32, u8p, u8p, u8p, u8p, vp, vp, vp, vp]
         L.orc_verify.restype = i32; L.orc_verify.argtypes = [vp, i32, u8p, sz, u8p, sz]
+        L.orc_setup.restype = i32
+        L.orc_setup.argtypes = [vp, u8p, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
+        L.orc_free.argtypes = [vp]
         L.orc_pairing_selftest.restype = i32
         L.orc_field_const.argtypes = [i32, u8p]
         L.orc_init()
@@ -139,3 +142,15 @@ def aes_ctr_xor(key, nonce, counter, data):
     out = C.create_string_buffer(len(data))
     lib().orc_aes_ctr_xor(bytes(key), len(key), bytes(nonce), counter, bytes(data), out, len(data))
     return out.raw
+
+
+def setup(cs: R1CS, seed: bytes):
+    """TEST keys in gnark layout (pk bytes, vk bytes) for a constraint system, deterministic in `seed` (32 bytes)."""
+    pk, vk = C.c_void_p(), C.c_void_p()
+    npk, nvk = C.c_size_t(), C.c_size_t()
+    rc = lib().orc_setup(cs.h, bytes(seed), C.byref(pk), C.byref(npk), C.byref(vk), C.byref(nvk))
+    if rc:
+        raise RuntimeError("oracle setup failed rc=%d" % rc)
+    out = C.string_at(pk, npk.value), C.string_at(vk, nvk.value)
+    lib().orc_free(pk); lib().orc_free(vk)
+    return out
