@@ -72,3 +72,23 @@ def gsc_chacha(gsc):
     """libprove with ChaCha20-V3 initialised from the reference's shipped key files (GPU only)."""
     assert gsc.init_algorithm(gsc.CHACHA20, golden_bytes("pk.chacha20"), golden_bytes("r1cs.chacha20"))
     return gsc
+
+
+AES = {"aes128": (1, "aes-128-ctr", 16), "aes256": (2, "aes-256-ctr", 32)}
+
+
+@pytest.fixture(scope="session")
+def aes_keys(oracle):
+    """TEST keys for the AES-V2 circuits from the oracle's Setup (the reference ships no pk.aes128 / pk.aes256:
+    .MISSING_LARGE_BLOBS).  Deterministic in the seed; cached under build/keys."""
+    out = {}
+    cache = os.path.join(ROOT, "build", "keys")
+    os.makedirs(cache, exist_ok=True)
+    for name, (algo, cipher, keylen) in AES.items():
+        r1cs = golden_bytes("r1cs." + name)
+        pkp, vkp = os.path.join(cache, "pk." + name), os.path.join(cache, "vk." + name)
+        if not (os.path.exists(pkp) and os.path.exists(vkp)):
+            pk, vk = oracle.setup(oracle.R1CS(r1cs), bytes([algo] * 32))
+            open(pkp, "wb").write(pk); open(vkp, "wb").write(vk)
+        out[name] = (r1cs, open(pkp, "rb").read(), open(vkp, "rb").read())
+    return out

@@ -121,8 +121,10 @@ def test_error_reporting_matches_reference_conventions(gsc_chacha):
     bad = json.loads(g.prove({"cipher": "aes-256-ctr1", "key": [0] * 32, "nonce": [0] * 12, "counter": [0, 1], "input": [0] * 64}))
     assert bad["Field"] == "counter" and bad["Value"] == "array" and bad["Struct"] == "InputParams" and "proof" not in bad
     assert json.loads(g.prove({"cipher": "aes-256-ctr1", "key": [], "nonce": [], "counter": 0, "input": []})) == "could not find prover foraes-256-ctr1"
-    assert json.loads(g.prove({"cipher": "aes-128-ctr", "key": [0] * 16, "nonce": [0] * 12, "counter": 0, "input": [0] * 64})) == \
-        "proving params are not initialized for cipher: aes-128-ctr"
+    aes_untouched = g.describe(g.AES_128) == "not initialised"        # other test modules may have initialised it in this process
+    if aes_untouched:
+        assert json.loads(g.prove({"cipher": "aes-128-ctr", "key": [0] * 16, "nonce": [0] * 12, "counter": 0, "input": [0] * 64})) == \
+            "proving params are not initialized for cipher: aes-128-ctr"
     assert json.loads(g.prove({"cipher": "chacha20", "key": [0] * 31, "nonce": [0] * 12, "counter": 0, "input": [0] * 64})) == "key length must be 32: 31"
     assert json.loads(g.prove({"cipher": "chacha20", "key": [0] * 32, "nonce": [0] * 11, "counter": 0, "input": [0] * 64})) == "nonce length must be 12: 11"
     assert json.loads(g.prove({"cipher": "chacha20", "key": [0] * 32, "nonce": [0] * 12, "counter": 0, "input": [0] * 65})) == "plaintext length must be 64: 65"
@@ -135,4 +137,6 @@ def test_error_reporting_matches_reference_conventions(gsc_chacha):
     assert g.init_algorithm(g.CHACHA20, b"", b"") is True
     assert g.init_algorithm(7, b"x", b"y") is False
     # garbage key material for a not-yet-initialised algorithm is refused, never crashes
-    assert g.init_algorithm(g.AES_128, b"\x00" * 100, b"\x01" * 100) is False
+    if aes_untouched:
+        assert g.init_algorithm(g.AES_128, b"\x00" * 100, b"\x01" * 100) is False
+        assert g.init_algorithm(g.AES_128, golden_bytes("pk.chacha20"), golden_bytes("r1cs.chacha20")) is False   # wrong circuit for the id

@@ -144,3 +144,39 @@ def test_aes_solver_satisfies_every_constraint(oracle, name, cipher, keylen, cou
     # counter > 2^32-5 is unprovable: the circuit asserts counter+b <= 2^32-1 (circuits/aesV2/aes128.go:41-53)
     rc, _ = cs.solve(cipher, key, nonce, 0xFFFFFFFE, pt, dump=False)
     assert rc != 0
+
+
+def test_setup_reproduces_reference_key_structure_and_own_keys_verify(oracle):
+    # Setup with the oracle on the ChaCha R1CS must give a pk/vk with exactly the structure of the reference's files
+    # (same slice lengths => same infinity filtering, same sizes), and a proof made with those keys must verify.
+    cs = oracle.R1CS(golden_bytes("r1cs.chacha20"))
+    pkb, vkb = oracle.setup(cs, bytes(range(32)))
+    assert len(pkb) == len(golden_bytes("pk.chacha20")) and len(vkb) == len(golden_bytes("vk.chacha20"))
+    pk, vk = oracle.ProvingKey(pkb), oracle.VerifyingKey(vkb)
+    assert (pk.n, pk.nA, pk.nB, pk.nZ, pk.nK, pk.nB2) == (32768, 22001, 12529, 32767, 22128, 12529)
+    assert pkb[8:168] == golden_bytes("pk.chacha20")[8:168]            # domain constants: 1/n, omega, 1/omega, g, 1/g
+    proof, ct = oracle.prove(cs, pk, "chacha20", KAT["key"], KAT["nonce"], KAT["counter"], KAT["input"], 5, 7)
+    assert oracle.verify(vk, "chacha20", proof, ct + KAT["nonce"] + KAT["counter"].to_bytes(4, "little") + KAT["input"])
+    assert pkb == oracle.setup(cs, bytes(range(32)))[0]                # deterministic in the seed
+
+
+@pytest.mark.parametrize("name", ["aes128", "aes256"])
+def test_aes_oracle_prove_verify_with_own_keys(oracle, aes_keys, name):
+    from conftest import AES
+    algo, cipher, keylen = AES[name]
+    r1cs, pkb, vkb = aes_keys[name]
+    assert len(vkb) == len(golden_bytes("vk." + name)) == 5008        # same vk layout as the reference's vk.aes*
+    cs, pk, vk = oracle.R1CS(r1cs), oracle.ProvingKey(pkb), oracle.VerifyingKey(vkb)
+    assert pk.n == 131072 and pk.nZ == 131071 and pk.n_ck == 1 and pk.n_basis == cs.n_committed and vk.nK == 143
+    rnd = random.Random(algo)
+    key, nonce, pt = rnd.randbytes(keylen), rnd.randbytes(12), rnd.randbytes(64)
+    proof, ct = oracle.prove(cs, pk, cipher, key, nonce, 9, pt, 111, 222, mask=333)
+    assert len(proof) == 196
+    sig = ct + nonce + (9).to_bytes(4, "big") + pt
+    assert oracle.verify(vk, cipher, proof, sig)
+    for pos in (3, 140, 170):                                           # Ar / commitment / PoK tampering
+        bad = bytearray(proof); bad[pos] ^= 1
+        assert not oracle.verify(vk, cipher, bytes(bad), sig)
+    # a different mask changes the proof but not its validity (commitment hiding)
+    proof2, _ = oracle.prove(cs, pk, cipher, key, nonce, 9, pt, 111, 222, mask=334)
+    assert proof2 != proof and oracle.verify(vk, cipher, proof2, sig)
