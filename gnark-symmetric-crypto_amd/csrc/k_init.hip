@@ -5,6 +5,7 @@
 // decompress the key, plus what gnark precomputes in its fft.Domain.  The digit tables are new: they trade
 // the 288 GB of HBM for the bucket pass of Pippenger.
 #include "kernels.hpp"
+#include "bn254_fp29.hpp"
 
 namespace gsc {
 using namespace bn254;
@@ -120,40 +121,49 @@ __global__ void k_fr_inverse(const fe* in, fe* out, size_t n) {
     out[i] = Fr::inv(in[i]);
 }
 
+// Montgomery value of the 8 x 32-bit domain (R = 2^256, what the decompression kernels produce) -> radix-2^29 domain (R' = 2^261)
+__device__ __forceinline__ fe9 to_fp29(const fe& old_mont) { return Fp29::to_mont(Fp29::unpack(Fp::from_mont(old_mont))); }
+__device__ __forceinline__ Aff9<Fp29f> base_to_fp29(const Aff<Fp>* b) { return Aff9<Fp29f>{to_fp29(b->x), to_fp29(b->y)}; }
+__device__ __forceinline__ Aff9<Fp2x> base_to_fp29(const Aff<Fp2>* b) {
+    return Aff9<Fp2x>{fe9x2{to_fp29(b->x.a0), to_fp29(b->x.a1)}, fe9x2{to_fp29(b->y.a0), to_fp29(b->y.a1)}};
+}
+
 // One thread per table row (base k, window j).  Forward pass: E_d = d*Bj in XYZZ, parked in `scratch`, with the running
 // product of the ZZZ_d parked in the row's own slots; one inversion per row; the backward pass turns every E_d into
 // its affine form (Montgomery batch inversion).  Rows [row0, row0 + nrows) are processed; scratch holds nrows*D points.
-template <class F>
-__global__ void k_build_table(const Aff<F>* bases, size_t row0, size_t nrows, int c, int nwin, Aff<F>* table, Xyzz<F>* scratch) {
-    using C = Curve<F>;
+// Table entries and scratch are memory images of radix-2^29 values (bn254_fp29.hpp).
+template <class F, class OldF>
+__global__ void k_build_table(const Aff<OldF>* bases, size_t row0, size_t nrows, int c, int nwin, fe* table, fe* scratch) {
+    using C = Curve9<F>;
     using E = typename F::E;
+    constexpr int CW = F::WORDS;              // field elements per coordinate
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nrows) return;
     size_t row = row0 + t;
     size_t k = row / nwin; int j = (int)(row % nwin);
     const size_t D = (size_t)1 << (c - 1);
-    Xyzz<F> P = C::from_aff(bases[k]);
+    Xyzz9<F> P = C::from_aff(base_to_fp29(bases + k));
     for (int q = 0; q < c * j; q++) P = C::dbl(P);
-    Aff<F> Bj = C::to_aff(P);
-    Aff<F>* out = table + row * D;
-    Xyzz<F>* sc = scratch + t * D;
-    Xyzz<F> Ed = C::from_aff(Bj);
+    Aff9<F> Bj = C::to_aff(P);
+    fe* out = table + row * D * (2 * CW);
+    fe* sc = scratch + t * D * (4 * CW);
+    Xyzz9<F> Ed = C::from_aff(Bj);
     E prefix = F::one();
     for (size_t d = 1; d <= D; d++) {
-        if (d > 1) Ed = C::madd(Ed, Bj);
-        sc[d - 1] = Ed;
-        out[d - 1].x = prefix;                 // product of ZZZ_1 .. ZZZ_{d-1}
+        if (d > 1) Ed = C::template madd<true>(Ed, Bj);
+        C::store_xyzz(sc + (d - 1) * (4 * CW), Ed);
+        F::store(out + (d - 1) * (2 * CW), prefix);                 // product of ZZZ_1 .. ZZZ_{d-1}
         prefix = F::mul(prefix, Ed.zzz);
     }
     E inv = F::inv(prefix);
     for (size_t d = D; d >= 1; d--) {
-        Ed = sc[d - 1];
-        E pre = out[d - 1].x;
+        Ed = C::load_xyzz(sc + (d - 1) * (4 * CW));
+        E pre = F::load(out + (d - 1) * (2 * CW));
         E izzz = F::mul(inv, pre);             // 1 / ZZZ_d
         inv = F::mul(inv, Ed.zzz);
         E izz = F::mul(F::sqr(Ed.zz), F::sqr(izzz));   // 1/ZZ = ZZ^2 / ZZZ^2
-        Aff<F> a; a.x = F::mul(Ed.x, izz); a.y = F::mul(Ed.y, izzz);
-        out[d - 1] = a;
+        Aff9<F> a; a.x = F::mul(Ed.x, izz); a.y = F::mul(Ed.y, izzz);
+        C::store_aff(out + (d - 1) * (2 * CW), a);
     }
 }
 
@@ -198,12 +208,12 @@ void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fr_inverse, dim3(blocks_for(n, 64)), dim3(64), 0, s, in, out, n);
 }
 void launch_build_table_g1(const G1Aff* bases, size_t row0, size_t nrows, int c, int nwin, G1Aff* table, G1Xyzz* scratch, hipStream_t s) {
-    if (nrows) hipLaunchKernelGGL(k_build_table<Fp>, dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
-                                  reinterpret_cast<const Aff<Fp>*>(bases), row0, nrows, c, nwin, reinterpret_cast<Aff<Fp>*>(table), reinterpret_cast<Xyzz<Fp>*>(scratch));
+    if (nrows) hipLaunchKernelGGL((k_build_table<Fp29f, Fp>), dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
+                                  reinterpret_cast<const Aff<Fp>*>(bases), row0, nrows, c, nwin, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
 }
 void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c, int nwin, G2Aff* table, G2Xyzz* scratch, hipStream_t s) {
-    if (nrows) hipLaunchKernelGGL(k_build_table<Fp2>, dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
-                                  reinterpret_cast<const Aff<Fp2>*>(bases), row0, nrows, c, nwin, reinterpret_cast<Aff<Fp2>*>(table), reinterpret_cast<Xyzz<Fp2>*>(scratch));
+    if (nrows) hipLaunchKernelGGL((k_build_table<Fp2x, Fp2>), dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
+                                  reinterpret_cast<const Aff<Fp2>*>(bases), row0, nrows, c, nwin, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
 }
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
                           fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s) {

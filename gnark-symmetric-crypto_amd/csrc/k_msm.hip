@@ -10,6 +10,7 @@
 // scalar loads are coalesced (2 KiB per wave) and the table gathers of a wave fall into one 2^(c-1)*64 B row.
 // Partial sums per (slice of bases, proof) are reduced with wavefront __shfl_xor butterflies.
 #include "kernels.hpp"
+#include "bn254_fp29.hpp"
 
 namespace gsc {
 using namespace bn254;
@@ -17,21 +18,6 @@ using namespace bn254;
 namespace {
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
-template <class F> struct AffLoader;
-template <> struct AffLoader<Fp> {
-    __device__ __forceinline__ static Aff<Fp> load(const void* table, size_t idx) {
-        const fe* q = reinterpret_cast<const fe*>(table) + 2 * idx;
-        return Aff<Fp>{load_fe(q), load_fe(q + 1)};
-    }
-};
-template <> struct AffLoader<Fp2> {
-    __device__ __forceinline__ static Aff<Fp2> load(const void* table, size_t idx) {
-        const fe* q = reinterpret_cast<const fe*>(table) + 4 * idx;
-        Aff<Fp2> a; a.x.a0 = load_fe(q); a.x.a1 = load_fe(q + 1); a.y.a0 = load_fe(q + 2); a.y.a1 = load_fe(q + 3);
-        return a;
-    }
-};
 
 // |s| <= (r-1)/2 after sign normalisation; returns true when the point must be negated
 __device__ __forceinline__ bool sign_normalise(fe& s) {
@@ -66,15 +52,13 @@ __device__ __forceinline__ uint32_t bits_at(const fe& s, uint32_t pos, uint32_t 
     return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
-template <class F>
-__global__ __launch_bounds__(64) void k_msm(MsmArgs a) {
-    using C = Curve<F>;
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const size_t slice = blockIdx.y;
-    const size_t per = (a.nbases + a.nslices - 1) / a.nslices;
-    const size_t k0 = slice * per, k1 = k0 + per < a.nbases ? k0 + per : a.nbases;
+// One slice of bases for one proof (lane).  EXACT = false is the hot path (no degenerate-case tests inside madd).
+template <class F, bool EXACT>
+__device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0, size_t k1, size_t p) {
+    using C = Curve9<F>;
     const uint32_t c = a.c, nwin = a.nwin, D = 1u << (c - 1);
-    Xyzz<F> acc = C::inf();
+    const fe* table = reinterpret_cast<const fe*>(a.table);
+    Xyzz9<F> acc = C::infinity();
     for (size_t k = k0; k < k1; k++) {
         const size_t row = a.rows ? uni(a.rows[k]) : k;
         fe s = load_fe(a.scalars + row * a.batch + p);
@@ -92,42 +76,56 @@ __global__ __launch_bounds__(64) void k_msm(MsmArgs a) {
             bool dneg = false;
             if (raw > D) { raw = (1u << c) - raw; dneg = true; carry = 1; } else carry = 0;
             if (raw) {
-                Aff<F> e = AffLoader<F>::load(a.table, ((size_t)k * nwin + j) * D + (raw - 1));
-                if (dneg != neg) e.y = F::neg(e.y);
-                acc = C::madd(acc, e);
+                Aff9<F> e = C::load_aff(table + (((size_t)k * nwin + j) * D + (raw - 1)) * (2 * F::WORDS));
+                if (dneg != neg) e.y = F::neg(e.y);           // signed-tight: fine as a product operand
+                acc = C::template madd<EXACT>(acc, e);
             }
         }
     }
-    Xyzz<F>* out = reinterpret_cast<Xyzz<F>*>(a.partial);
-    out[slice * a.batch + p] = acc;
+    return acc;
 }
 
-__device__ __forceinline__ fe shfl_xor_fe(const fe& v, int m) {
-    fe r;
+template <class F>
+__global__ __launch_bounds__(64) void k_msm(MsmArgs a) {
+    using C = Curve9<F>;
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t slice = blockIdx.y;
+    const size_t per = (a.nbases + a.nslices - 1) / a.nslices;
+    const size_t k0 = slice * per, k1 = k0 + per < a.nbases ? k0 + per : a.nbases;
+    Xyzz9<F> acc = accumulate_slice<F, false>(a, k0, k1, p);
+    // A degenerate step (accumulator == +-entry) zeroes ZZ for good; it cannot be told from a genuine point at infinity
+    // without the exact tests, so the (very rare) lane is recomputed with them.
+    if (!acc.inf && F::is_zero(acc.zz)) acc = accumulate_slice<F, true>(a, k0, k1, p);
+    C::store_xyzz(reinterpret_cast<fe*>(a.partial) + (slice * a.batch + p) * (4 * F::WORDS), acc);
+}
+
+__device__ __forceinline__ fe9 shfl_xor_e(const fe9& v, int m) {
+    fe9 r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__shfl_xor((int)v.l[i], m);
+    for (int i = 0; i < 9; i++) r.l[i] = __shfl_xor(v.l[i], m);
     return r;
 }
-__device__ __forceinline__ fe2 shfl_xor_fe(const fe2& v, int m) { return fe2{shfl_xor_fe(v.a0, m), shfl_xor_fe(v.a1, m)}; }
+__device__ __forceinline__ fe9x2 shfl_xor_e(const fe9x2& v, int m) { return fe9x2{shfl_xor_e(v.a0, m), shfl_xor_e(v.a1, m)}; }
 
 // one wave sums up to 64 slices of one proof: lanes = slices, butterfly over __shfl_xor
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_reduce(const Xyzz<F>* partial, size_t nslices, size_t batch, Xyzz<F>* out) {
-    using C = Curve<F>;
+__global__ __launch_bounds__(64) void k_msm_reduce(const fe* partial, size_t nslices, size_t batch, fe* out) {
+    using C = Curve9<F>;
     const size_t p = blockIdx.x, grp = blockIdx.y;
     const size_t slice = grp * 64 + threadIdx.x;
-    Xyzz<F> v = slice < nslices ? partial[slice * batch + p] : C::inf();
+    Xyzz9<F> v = slice < nslices ? C::load_xyzz(partial + (slice * batch + p) * (4 * F::WORDS)) : C::infinity();
     for (int m = 32; m >= 1; m >>= 1) {
-        Xyzz<F> o;
-        o.x = shfl_xor_fe(v.x, m); o.y = shfl_xor_fe(v.y, m); o.zz = shfl_xor_fe(v.zz, m); o.zzz = shfl_xor_fe(v.zzz, m);
+        Xyzz9<F> o;
+        o.x = shfl_xor_e(v.x, m); o.y = shfl_xor_e(v.y, m); o.zz = shfl_xor_e(v.zz, m); o.zzz = shfl_xor_e(v.zzz, m);
+        o.inf = __shfl_xor((int)v.inf, m) != 0;
         v = C::add(v, o);
     }
-    if (threadIdx.x == 0) out[grp * batch + p] = v;
+    if (threadIdx.x == 0) C::store_xyzz(out + (grp * batch + p) * (4 * F::WORDS), v);
 }
 
 // ---- proof assembly ----
-__device__ __forceinline__ void store_canon(uint8_t* dst, const fe& mont) {
-    fe c = Fp::from_mont(mont);
+__device__ __forceinline__ void store_canon(uint8_t* dst, const fe9& mont) {      // canonical integer, 8 little-endian words
+    const fe c = Fp29::pack(Fp29::from_mont(mont));
     uint32_t* q = reinterpret_cast<uint32_t*>(dst);
 #pragma unroll
     for (int i = 0; i < 8; i++) q[i] = c.l[i];
@@ -139,21 +137,21 @@ __global__ __launch_bounds__(64) void k_fin_scalarmul(const G1Xyzz* sumA, const 
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     const int role = blockIdx.y;
     if (p >= batch) return;
-    const Xyzz<Fp>* src = reinterpret_cast<const Xyzz<Fp>*>(role == 0 ? sumA : sumB1) + p;
-    Xyzz<Fp> P = *src;
+    const fe* src = reinterpret_cast<const fe*>(role == 0 ? sumA : sumB1) + 4 * p;
+    Xyzz9<Fp29f> P = G1x::load_xyzz(src);
     const uint32_t* sc = reinterpret_cast<const uint32_t*>(rs + 64 * p) + (role == 0 ? 8 : 0);   // role 0 uses s, role 1 uses r
-    Xyzz<Fp> acc = G1::inf();
-    if (!G1::is_inf(P)) {
-        Aff<Fp> A = G1::to_aff(P);
+    Xyzz9<Fp29f> acc = G1x::infinity();
+    if (!P.inf) {
+        Aff9<Fp29f> A = G1x::to_aff(P);
         if (role == 0) { store_canon(out + 256 * p, A.x); store_canon(out + 256 * p + 32, A.y); }
         for (int i = 253; i >= 0; i--) {
-            acc = G1::dbl(acc);
-            if ((sc[i >> 5] >> (i & 31)) & 1u) acc = G1::madd(acc, A);
+            acc = G1x::dbl(acc);
+            if ((sc[i >> 5] >> (i & 31)) & 1u) acc = G1x::madd<true>(acc, A);
         }
     } else if (role == 0) {
         atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), 1u << (8 * (p & 3)));
     }
-    reinterpret_cast<Xyzz<Fp>*>(tmp)[(size_t)role * batch + p] = acc;
+    G1x::store_xyzz(reinterpret_cast<fe*>(tmp) + ((size_t)role * batch + p) * 4, acc);
 }
 __global__ __launch_bounds__(64) void k_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp,
                                                      size_t batch, uint8_t* out, uint8_t* flags) {
@@ -162,17 +160,15 @@ __global__ __launch_bounds__(64) void k_fin_combine(const G2Xyzz* sumB2, const G
     const int role = blockIdx.y;
     uint32_t fl = 0;
     if (role == 0) {
-        const Xyzz<Fp>* K = reinterpret_cast<const Xyzz<Fp>*>(sumK);
-        const Xyzz<Fp>* Z = reinterpret_cast<const Xyzz<Fp>*>(sumZ);
-        const Xyzz<Fp>* T = reinterpret_cast<const Xyzz<Fp>*>(tmp);
-        Xyzz<Fp> v = G1::add(G1::add(K[p], Z[p]), G1::add(T[p], T[batch + p]));
-        if (G1::is_inf(v)) fl |= 4;
-        else { Aff<Fp> A = G1::to_aff(v); store_canon(out + 256 * p + 192, A.x); store_canon(out + 256 * p + 224, A.y); }
+        const fe* K = reinterpret_cast<const fe*>(sumK); const fe* Z = reinterpret_cast<const fe*>(sumZ); const fe* T = reinterpret_cast<const fe*>(tmp);
+        Xyzz9<Fp29f> v = G1x::add(G1x::add(G1x::load_xyzz(K + 4 * p), G1x::load_xyzz(Z + 4 * p)), G1x::add(G1x::load_xyzz(T + 4 * p), G1x::load_xyzz(T + 4 * (batch + p))));
+        if (v.inf) fl |= 4;
+        else { Aff9<Fp29f> A = G1x::to_aff(v); store_canon(out + 256 * p + 192, A.x); store_canon(out + 256 * p + 224, A.y); }
     } else {
-        Xyzz<Fp2> v = reinterpret_cast<const Xyzz<Fp2>*>(sumB2)[p];
-        if (G2::is_inf(v)) fl |= 2;
+        Xyzz9<Fp2x> v = G2x::load_xyzz(reinterpret_cast<const fe*>(sumB2) + 8 * p);
+        if (v.inf) fl |= 2;
         else {
-            Aff<Fp2> A = G2::to_aff(v);
+            Aff9<Fp2x> A = G2x::to_aff(v);
             store_canon(out + 256 * p + 64, A.x.a0); store_canon(out + 256 * p + 96, A.x.a1);
             store_canon(out + 256 * p + 128, A.y.a0); store_canon(out + 256 * p + 160, A.y.a1);
         }
@@ -183,11 +179,11 @@ __global__ __launch_bounds__(64) void k_fin_combine(const G2Xyzz* sumB2, const G
 __global__ void k_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit) {
     const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= batch) return;
-    Xyzz<Fp> v = reinterpret_cast<const Xyzz<Fp>*>(points)[p];
+    Xyzz9<Fp29f> v = G1x::load_xyzz(reinterpret_cast<const fe*>(points) + 4 * p);
     uint8_t* o = out + 64 * p;
-    if (G1::is_inf(v)) { for (int i = 0; i < 64; i++) o[i] = 0; atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), bit << (8 * (p & 3))); return; }
-    Aff<Fp> A = G1::to_aff(v);
-    fe x = Fp::from_mont(A.x), y = Fp::from_mont(A.y);
+    if (v.inf) { for (int i = 0; i < 64; i++) o[i] = 0; atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), bit << (8 * (p & 3))); return; }
+    Aff9<Fp29f> A = G1x::to_aff(v);
+    const fe x = Fp29::pack(Fp29::from_mont(A.x)), y = Fp29::pack(Fp29::from_mont(A.y));
     for (int i = 0; i < 8; i++) {
         const uint32_t xw = x.l[7 - i], yw = y.l[7 - i];
         o[4 * i] = (uint8_t)(xw >> 24); o[4 * i + 1] = (uint8_t)(xw >> 16); o[4 * i + 2] = (uint8_t)(xw >> 8); o[4 * i + 3] = (uint8_t)xw;
@@ -208,18 +204,18 @@ __global__ void k_challenge_from_hash(const uint8_t* h48, fe* commit, size_t bat
 }  // namespace
 
 void launch_msm_g1(const MsmArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm<Fp>, dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_msm<Fp29f>, dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
 }
 void launch_msm_g2(const MsmArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm<Fp2>, dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_msm<Fp2x>, dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
 }
 void launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_reduce<Fp>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
-                       reinterpret_cast<const Xyzz<Fp>*>(partial), nslices, batch, reinterpret_cast<Xyzz<Fp>*>(out));
+    hipLaunchKernelGGL(k_msm_reduce<Fp29f>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
+                       reinterpret_cast<const fe*>(partial), nslices, batch, reinterpret_cast<fe*>(out));
 }
 void launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_reduce<Fp2>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
-                       reinterpret_cast<const Xyzz<Fp2>*>(partial), nslices, batch, reinterpret_cast<Xyzz<Fp2>*>(out));
+    hipLaunchKernelGGL(k_msm_reduce<Fp2x>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
+                       reinterpret_cast<const fe*>(partial), nslices, batch, reinterpret_cast<fe*>(out));
 }
 void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s) {
     hipLaunchKernelGGL(k_points_to_affine_be, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, points, batch, out, flags, bit);

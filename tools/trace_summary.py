@@ -1,27 +1,23 @@
-"""Summarise a rocprofv3 kernel_trace.csv: per-kernel totals for the LAST batch plus solver gaps."""
-import csv, sys, collections
+"""Summarise a rocprofv3 kernel_trace.csv: per-kernel totals for the LAST batch."""
+import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last batch = after the last k_assign_chacha
 idx = max(i for i, r in enumerate(rows) if "k_assign" in r["Kernel_Name"])
 rows = rows[idx:]
 tot = collections.OrderedDict()
+def short(n):
+    m = re.search(r"(k_\w+)(<[^>]*>)?", n)
+    if not m: return n[:40]
+    t = m.group(1)
+    if "Fp2" in n.split("(")[0]: t += "<Fp2>"
+    elif "FpParams" in n.split("(")[0]: t += "<Fp>"
+    return t
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].split("::")[-1][:40]
+    name = short(r["Kernel_Name"])
+    if name.startswith("k_msm<") : name += " grid=%sx%s" % (int(r["Grid_Size_X"])//64, r["Grid_Size_Y"])
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     t = tot.setdefault(name, [0, 0]); t[0] += 1; t[1] += d
-for k, (c, d) in tot.items():
-    print("%-40s calls=%4d total=%9.3f ms avg=%9.1f us" % (k, c, d / 1e6, d / c / 1e3))
-sol = [r for r in rows if "k_solver" in r["Kernel_Name"]]
-if sol:
-    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sol]
-    gaps = [int(b["Start_Timestamp"]) - int(a["End_Timestamp"]) for a, b in zip(sol, sol[1:])]
-    print("solver: span %.3f ms, sum durations %.3f ms, sum gaps %.3f ms, max dur %.1f us, median dur %.1f us, median gap %.1f us" % (
-        (int(sol[-1]["End_Timestamp"]) - int(sol[0]["Start_Timestamp"])) / 1e6, sum(durs) / 1e6, sum(gaps) / 1e6, max(durs) / 1e3, sorted(durs)[len(durs) // 2] / 1e3, sorted(gaps)[len(gaps) // 2] / 1e3))
-    top = sorted(zip(durs, [r["Grid_Size_Y"] for r in sol]), reverse=True)[:8]
-    print("longest solver levels (us, gridY):", [(round(d / 1e3, 1), g) for d, g in top])
 span = int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])
+for k, (c, d) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+    print("%-42s calls=%4d total=%9.3f ms (%4.1f%%) avg=%9.1f us" % (k, c, d / 1e6, 100.0 * d / span, d / c / 1e3))
 print("batch span %.3f ms" % (span / 1e6))
-if sol:
-    print("first 24 solver levels (us, gridY):", [(round(d / 1e3, 1), r["Grid_Size_Y"]) for d, r in list(zip(durs, sol))[:24]])
-    print("scratch/vgpr:", sol[0]["Scratch_Size"], sol[0]["VGPR_Count"])
