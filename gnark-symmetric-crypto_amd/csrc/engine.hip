@@ -81,7 +81,7 @@ class AlgorithmImpl {
 
     // program
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
-    uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; int has_div = 0;
+    uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; std::vector<uint32_t> level_long; int has_div = 0;
     // NTT
     DevBuf<fe> tw_fwd, tw_inv, scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
     // MSM sets
@@ -116,7 +116,7 @@ class AlgorithmImpl {
         SolverProgram sp = build_solver_program(cs);
         n_levels = (uint32_t)sp.n_levels; commit_level = (uint32_t)sp.commit_level; has_div = sp.n_inversions ? 1 : 0;
         level_width.resize(n_levels); for (uint32_t l = 0; l < n_levels; l++) level_width[l] = sp.sched[2 + l] - sp.sched[1 + l];
-        level_kind = sp.level_kind;
+        level_kind = sp.level_kind; level_long = sp.level_long;
         prog.alloc(sp.words.size()); prog.upload(sp.words.data(), sp.words.size(), stream);
         sched.alloc(sp.sched.size()); sched.upload(sp.sched.data(), sp.sched.size(), stream);
         lookup_coeff.alloc(sp.lookup_coeff.size() ? sp.lookup_coeff.size() : 1);
@@ -318,11 +318,11 @@ class AlgorithmImpl {
         launch_prep_rs(d_rs.p, d_W.p, n_wires, B, has_commitment ? d_mask_in.p : nullptr, d_mask.p, stream);
         HIP_CHECK(hipMemsetAsync(d_status.p, 0xFF, B * 4, stream));
         SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p,
-                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, env_int("GSC_DBG", 0), d_dbg.p};
+                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, 0u, env_int("GSC_DBG", 0), d_dbg.p};
         if (sa.dbg & 32) HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 16, stream));
         auto run_levels = [&](uint32_t from, uint32_t to) {
             for (uint32_t l = from; l < to; l++) {
-                sa.first_level = l;
+                sa.first_level = l; sa.n_long = level_long[l];
                 if (level_kind[l]) launch_solver_count_level(sa, level_width[l], stream); else launch_solver_level(sa, level_width[l], stream);
             }
         };

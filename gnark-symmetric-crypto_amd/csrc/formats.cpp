@@ -1,6 +1,7 @@
 // Host-side decoders (see formats.hpp).  Format authority: SURVEY.md App. A / App. B, verified against
 // the reference's shipped circuits/generated/{r1cs,pk}.* files.
 #include "formats.hpp"
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 
@@ -398,6 +399,15 @@ SolverProgram build_solver_program(const R1csFile& cs) {
     sp.count_ops = count_ops;
     sp.n_levels = levels.size();
     if (sp.commit_level == (size_t)-1) sp.commit_level = sp.n_levels;
+    // inside a level, long ops first: the solver gives each of them a whole workgroup (its waves split the terms)
+    auto op_words = [&](uint32_t off) { return W[off] >> 8; };
+    for (size_t l = 0; l < levels.size(); l++) {
+        auto& v = levels[l];
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return op_words(x) > op_words(y); });
+        uint32_t nlong = 0;
+        if (!sp.level_kind[l]) while (nlong < v.size() && op_words(v[nlong]) > SolverProgram::LONG_OP_WORDS) nlong++;
+        sp.level_long.push_back(nlong);
+    }
     sp.sched.push_back((uint32_t)sp.n_levels);
     uint32_t run = 0;
     for (auto& l : levels) { sp.sched.push_back(run); run += (uint32_t)l.size(); if (l.size() > sp.max_level_width) sp.max_level_width = l.size(); }

@@ -80,6 +80,8 @@ struct SolverProgram {
     // [0, commit_level), computes the commitment, then runs [commit_level, n_levels).  Otherwise commit_level == n_levels.
     std::vector<uint32_t> sched;
     std::vector<uint8_t> level_kind;         // per level: 0 = generic ops (k_solver), 1 = OP_COUNT histogram ops (k_solver_count)
+    std::vector<uint32_t> level_long;        // per level: its first level_long[l] ops are "long" (more than LONG_OP_WORDS words)
+    static constexpr uint32_t LONG_OP_WORDS = 48;
     std::vector<uint32_t> count_ops;         // word offsets of the OP_COUNT ops (checked on the device at init)
     size_t n_levels = 0, commit_level = 0, max_level_width = 0;
     size_t n_ops = 0, n_inversions = 0;

@@ -56,11 +56,13 @@ __device__ __forceinline__ uint32_t limb_at(const fe& v, uint32_t i) {
 // round), then folded by a rolled loop so that the code — in particular the Montgomery product — exists once.
 // Code size matters here: every wave runs this straight-line path once, so instruction-cache misses dominate
 // if the body is unrolled (measured: 330 KB of code made a level take 170 us instead of ~20).
-__device__ __forceinline__ fe eval_expr(Window& win, uint32_t at, const fe* coeff, const fe* W, size_t batch, size_t p, uint32_t& next, int dbg) {
+// part / nparts: the chunks of the expression are dealt round-robin to `nparts` cooperating waves; the caller adds the partial sums.
+__device__ __forceinline__ fe eval_expr(Window& win, uint32_t at, const fe* coeff, const fe* W, size_t batch, size_t p, uint32_t& next, int dbg,
+                                        uint32_t part = 0, uint32_t nparts = 1) {
     const uint32_t n = win.get(at);
     next = at + 1 + 2 * n;
     fe acc = Fr::zero();
-    for (uint32_t k0 = 0; k0 < n; k0 += 8) {
+    for (uint32_t k0 = 8 * part; k0 < n; k0 += 8 * nparts) {
         const uint32_t t0 = at + 1 + 2 * k0;
         win.ensure(t0, 16);                                   // the whole chunk inside the window
         uint32_t cidv[8], widv[8];                            // wave-uniform: scalar registers
@@ -114,10 +116,13 @@ __device__ __forceinline__ fe eval_expr(Window& win, uint32_t at, const fe* coef
     return acc;
 }
 
-// One launch per level (the kernel boundary is the inter-level barrier and makes the previous level's stores
-// visible chip-wide); grid = (proof groups of 64, ceil(ops in level / WPB)); one op per wave.
+// One launch per level (the kernel boundary is the inter-level barrier and makes the previous level's stores visible
+// chip-wide); grid = (proof groups of 64, ops in the level); one op per workgroup.  The WPB waves of the workgroup split
+// the chunks of the op's linear expressions (ChaCha's add32 rows have 130 terms and would otherwise be one wave's serial
+// work — a lone wave issues an instruction only every ~9 cycles) and combine the partial sums through LDS.
 template <bool HAS_DIV>
 __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
+    __shared__ uint32_t s_part[3][WPB][8][64];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t p = (size_t)blockIdx.x * 64 + lane;
     const size_t batch = a.batch;
@@ -125,48 +130,56 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
     const uint32_t* lstart = a.sched + 1;
     const uint32_t* ops = a.sched + 2 + nlev;
     const uint32_t lev = a.first_level;
-    const uint32_t i = lstart[lev] + blockIdx.y * WPB + wave;
-    if (i >= lstart[lev + 1]) return;
+    // workgroups [0, n_long): one long op each, its terms split over the WPB waves;
+    // workgroups [n_long, ...): WPB short ops each, one per wave (the LDS exchange then has a single contributor)
+    const bool coop = blockIdx.y < a.n_long;
+    const uint32_t i = lstart[lev] + (coop ? blockIdx.y : a.n_long + (blockIdx.y - a.n_long) * WPB + wave);
+    const uint32_t part = coop ? wave : 0u, nparts = coop ? (uint32_t)WPB : 1u, slot = coop ? 0u : wave;
     const int dbg = a.dbg;
     if (dbg & 1) return;
-    unsigned long long t0c = 0, t0r = 0;
-    if (dbg & 32) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    if (i >= lstart[lev + 1]) return;          // only in wave-per-op workgroups, which never reach a barrier
     bool bad = false;
     Window win{a.prog, 0, 0, lane};
     const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)ops[i]);
     win.load(at);
     const uint32_t op = win.get(at) & 0xFF;
-    if (dbg & 2) return;
-    if (op == OP_R1C || op == OP_NBITS || op == OP_LOOKUP) {
-        // common shape: a run of linear expressions, each followed by an op-specific step
+    if (op == OP_R1C || op == OP_NBITS) {
         const uint32_t f1 = win.get(at + 1), f2 = win.get(at + 2), f3 = win.get(at + 3), f4 = win.get(at + 4);
-        const uint32_t nexpr = op == OP_R1C ? 3u : op == OP_NBITS ? 1u : f2;
-        uint32_t q = op == OP_R1C ? at + 5 : op == OP_NBITS ? at + 3 : at + 4;
-        fe va = Fr::zero(), vb = Fr::zero(), vc = Fr::zero();
+        const uint32_t nexpr = op == OP_R1C ? 3u : 1u;
+        uint32_t q = op == OP_R1C ? at + 5 : at + 3;
 #pragma unroll 1
         for (uint32_t e = 0; e < nexpr; e++) {
             uint32_t next;
-            fe r = eval_expr(win, q, a.coeff, a.W, batch, p, next, dbg);
-            if (dbg & 16) { if (e == nexpr - 1) store_fe(a.A + p, r); q = next; continue; }
+            const fe r = eval_expr(win, q, a.coeff, a.W, batch, p, next, dbg, part, nparts);
             q = next;
-            if (op == OP_R1C) { if (e == 0) va = r; else if (e == 1) vb = r; else vc = r; }
-            else {
-                r = Fr::from_mont(r);
-                if (op == OP_NBITS) {                       // [hdr, out0, nOut, expr]
-                    const fe one = Fr::one(), zero = Fr::zero();
-                    for (uint32_t k = 0; k < f2; k++) {
-                        const uint32_t bit = k < 256 ? (limb_at(r, k >> 5) >> (k & 31)) & 1u : 0u;
-                        store_fe(a.W + (size_t)(f1 + k) * batch + p, bit ? one : zero);
-                    }
-                } else {                                    // OP_LOOKUP [hdr, out0, nIn, table, exprs]
-                    const uint32_t hi = r.l[1] | r.l[2] | r.l[3] | r.l[4] | r.l[5] | r.l[6] | r.l[7];
-                    if (hi != 0 || r.l[0] >= 256) bad = true;
-                    const uint32_t cid = a.lookup_coeff[f3 * 256 + (r.l[0] & 255)];
-                    store_fe(a.W + (size_t)(f1 + e) * batch + p, load_fe(a.coeff + cid));
-                }
-            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) s_part[e][wave][k][lane] = r.l[k];       // own slot: no cross-wave hazard in wave-per-op mode
         }
-        if (op == OP_R1C) {                                 // [hdr, loc, constraint, unk_wire, unk_coeff, L, R, O]
+        fe v[3];
+        if (coop) { __syncthreads(); if (wave != 0) return; }
+#pragma unroll 1
+        for (uint32_t e = 0; e < nexpr; e++) {
+            fe acc;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc.l[k] = s_part[e][slot][k][lane];
+#pragma unroll 1
+            for (uint32_t w = 1; w < nparts; w++) {
+                fe t;
+#pragma unroll
+                for (int k = 0; k < 8; k++) t.l[k] = s_part[e][w][k][lane];
+                acc = Fr::add(acc, t);
+            }
+            if (e == 0) v[0] = acc; else if (e == 1) v[1] = acc; else v[2] = acc;
+        }
+        if (op == OP_NBITS) {                               // [hdr, out0, nOut, expr]
+            const fe r = Fr::from_mont(v[0]);
+            const fe one = Fr::one(), zero = Fr::zero();
+            for (uint32_t k = 0; k < f2; k++) {
+                const uint32_t bit = k < 256 ? (limb_at(r, k >> 5) >> (k & 31)) & 1u : 0u;
+                store_fe(a.W + (size_t)(f1 + k) * batch + p, bit ? one : zero);
+            }
+        } else {                                            // [hdr, loc, constraint, unk_wire, unk_coeff, L, R, O]
+            fe va = v[0], vb = v[1], vc = v[2];
             const uint32_t loc = f1, cidx = f2, uw = f3, uc = f4;
             fe ab = Fr::mul(va, vb);
             if (loc == 0) bad = !Fr::eq(ab, vc);
@@ -188,17 +201,28 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
             store_fe(a.B + (size_t)cidx * batch + p, vb);
             store_fe(a.C + (size_t)cidx * batch + p, vc);
         }
-    } else if (op == OP_RANDOMIZE || op == OP_COMMIT) {      // [hdr, out0, nOut]
-        const uint32_t o0 = win.get(at + 1), nout = win.get(at + 2);
-        const fe* src = op == OP_RANDOMIZE ? a.mask : a.commit;
-        fe v = src ? load_fe(src + p) : Fr::zero();
-        for (uint32_t k = 0; k < nout; k++) store_fe(a.W + (size_t)(o0 + k) * batch + p, v);
+    } else if (!coop || wave == 0) {
+        if (op == OP_LOOKUP) {                              // [hdr, out0, nIn, table, exprs]: out[e] = table[value of expr e]
+            const uint32_t o0 = win.get(at + 1), nin = win.get(at + 2), table = win.get(at + 3);
+            uint32_t q = at + 4;
+#pragma unroll 1
+            for (uint32_t e = 0; e < nin; e++) {
+                uint32_t next;
+                const fe r = Fr::from_mont(eval_expr(win, q, a.coeff, a.W, batch, p, next, dbg));
+                q = next;
+                const uint32_t hi = r.l[1] | r.l[2] | r.l[3] | r.l[4] | r.l[5] | r.l[6] | r.l[7];
+                if (hi != 0 || r.l[0] >= 256) bad = true;
+                const uint32_t cid = a.lookup_coeff[table * 256 + (r.l[0] & 255)];
+                store_fe(a.W + (size_t)(o0 + e) * batch + p, load_fe(a.coeff + cid));
+            }
+        } else if (op == OP_RANDOMIZE || op == OP_COMMIT) { // [hdr, out0, nOut]
+            const uint32_t o0 = win.get(at + 1), nout = win.get(at + 2);
+            const fe* src = op == OP_RANDOMIZE ? a.mask : a.commit;
+            fe v = src ? load_fe(src + p) : Fr::zero();
+            for (uint32_t k = 0; k < nout; k++) store_fe(a.W + (size_t)(o0 + k) * batch + p, v);
+        }
     }
     if (bad) atomicMin(a.status + p, i);     // status: 0xFFFFFFFF = satisfied, else first failing op
-    if ((dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
-        atomicAdd(a.dbg_out, (unsigned long long)(t1c - t0c)); atomicAdd(a.dbg_out + 1, (unsigned long long)(t1r - t0r));
-    }
 }
 
 // OP_COUNT (logderivarg.countHint): out[i] = number of query rows equal to table row i.  One wave per (64 proofs, op); the
@@ -336,7 +360,8 @@ void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint
 }
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
     if (!level_width) return;
-    const dim3 grid((unsigned)(a.batch / 64), (level_width + WPB - 1) / WPB), block(64 * WPB);
+    const uint32_t n_short = level_width - a.n_long;
+    const dim3 grid((unsigned)(a.batch / 64), a.n_long + (n_short + WPB - 1) / WPB), block(64 * WPB);
     // the division-free variant (ChaCha20-V3 never divides) carries no call to the inversion routine and so needs no
     // scratch memory: a kernel with scratch pays a per-dispatch setup that dominated the 163 short level launches
     if (a.has_div) hipLaunchKernelGGL(k_solver<true>, grid, block, 0, s, a);
