@@ -27,11 +27,8 @@ namespace bn254 {
 
 struct fe9 { int32_t l[9]; };
 
-struct Fp29 {
-    using E = fe9;
-    static constexpr int32_t MASK = (1 << 29) - 1;
+struct Fp29Q {     // base field p
     static constexpr uint32_t NINV = 75916169u;      // -p^-1 mod 2^29
-    DEVFN static constexpr int32_t P(int i) { constexpr int32_t v[9] = {410844487, 17064118, 477274959, 47522512, 361093496, 47923392, 10936641, 240920116, 3171406}; return v[i]; }
     DEVFN static constexpr int32_t ONE(int i) { constexpr int32_t v[9] = {360500257, 337389400, 408039635, 21759001, 178483129, 490881230, 299191303, 86689704, 903222}; return v[i]; }   // 2^261 mod p
     DEVFN static constexpr int32_t R2(int i) { constexpr int32_t v[9] = {94088208, 219480995, 25171640, 279645352, 40052281, 46143135, 379321683, 294034764, 2757030}; return v[i]; }       // 2^522 mod p
     // limb i of 2^s * p, s = 0..4 (each a tight representation)
@@ -45,6 +42,37 @@ struct Fp29 {
         return v[s][i];
     }
     DEVFN static constexpr int32_t HALF(int i) { constexpr int32_t v[9] = {205422243, 276967515, 238637479, 23761256, 180546748, 292397152, 5468320, 120460058, 1585703}; return v[i]; }   // (p-1)/2
+    DEVFN static constexpr uint32_t INVE(int i) { constexpr uint32_t v[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u}; return v[i]; }   // p-2
+};
+struct Fr29Q {     // scalar field r
+    static constexpr uint32_t NINV = 268435455u;     // -r^-1 mod 2^29
+    DEVFN static constexpr int32_t ONE(int i) { constexpr int32_t v[9] = {268435287, 514263732, 86771339, 391139145, 178784091, 490881230, 299191303, 86689704, 903222}; return v[i]; }
+    DEVFN static constexpr int32_t R2(int i) { constexpr int32_t v[9] = {95853524, 102173274, 34397646, 498479371, 240439551, 486036963, 471195907, 131109217, 656714}; return v[i]; }
+    DEVFN static constexpr int32_t PK(int s, int i) {
+        constexpr int32_t v[5][9] = {
+            {268435457, 521120927, 240919632, 131109107, 361091715, 47923392, 10936641, 240920116, 3171406},
+            {2, 505370943, 481839265, 262218214, 185312518, 95846785, 21873282, 481840232, 6342812},
+            {4, 473870974, 426807619, 524436429, 370625036, 191693570, 43746564, 426809552, 12685625},
+            {8, 410871036, 316744327, 512001947, 204379161, 383387141, 87493128, 316748192, 25371251},
+            {16, 284871160, 96617743, 487132983, 408758323, 229903370, 174986257, 96625472, 50742503}};
+        return v[s][i];
+    }
+    DEVFN static constexpr int32_t HALF(int i) { constexpr int32_t v[9] = {402653184, 260560463, 388895272, 333990009, 180545857, 292397152, 5468320, 120460058, 1585703}; return v[i]; }
+    DEVFN static constexpr uint32_t INVE(int i) { constexpr uint32_t v[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u}; return v[i]; }   // r-2
+    // 2^266 mod r = R'^2 / 2^256: Montgomery-multiplying a value of the 2^256 domain by this constant lands in the 2^261 domain
+    DEVFN static constexpr int32_t FROM_R256(int i) { constexpr int32_t v[9] = {268430039, 492061940, 71535269, 62181526, 323781850, 244503300, 348886451, 68918589, 360451}; return v[i]; }
+};
+
+template <class Q>
+struct Field29 {
+    using E = fe9;
+    static constexpr int32_t MASK = (1 << 29) - 1;
+    static constexpr uint32_t NINV = Q::NINV;
+    DEVFN static constexpr int32_t P(int i) { return Q::PK(0, i); }
+    DEVFN static constexpr int32_t ONE(int i) { return Q::ONE(i); }
+    DEVFN static constexpr int32_t R2(int i) { return Q::R2(i); }
+    DEVFN static constexpr int32_t PK(int s, int i) { return Q::PK(s, i); }
+    DEVFN static constexpr int32_t HALF(int i) { return Q::HALF(i); }
 
     DEVFN static E zero() { E r;
 #pragma unroll
@@ -172,7 +200,9 @@ struct Fp29 {
         return acc;
     }
     DEVFN static E inv(const E& a) {      // Fermat; 0 -> 0
-        const uint32_t e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        uint32_t e[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = Q::INVE(i);
         return pow(a, e);
     }
     // canonical value of a Montgomery element > (p-1)/2 ?
@@ -182,6 +212,9 @@ struct Fp29 {
         return false;
     }
 };
+
+using Fp29 = Field29<Fp29Q>;
+using Fr29 = Field29<Fr29Q>;
 
 // ---- Fp2 = Fp[u]/(u^2+1).  mul/sqr/inv take signed-tight components (|limb| < 2^29) and return tight ones. ----
 struct fe9x2 { fe9 a0, a1; };

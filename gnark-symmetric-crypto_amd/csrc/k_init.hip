@@ -175,19 +175,28 @@ __device__ __forceinline__ fe fr_pow_u32(const fe& a, uint32_t e) {
     }
     return acc;
 }
+// Values are produced with the 8 x 32-bit scalar field and stored as memory images of the radix-2^29 field used by the NTT
+// kernels (bn254_fp29.hpp): twiddles and den_inv in its Montgomery domain (2^261); scale_mid additionally carries the factor
+// 2^261/2^256 that moves the solver's a/b/c values (2^256 domain) into that domain; scale_out is a plain integer so that the
+// last product of the pipeline leaves Montgomery form.
+__device__ __forceinline__ fe to_fr29_image(const fe& old_mont) { return Fr29::pack(Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(old_mont))))); }
 __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
                                 fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 1u << L;
     if (i >= n) return;
-    if (i < n / 2) { tw_fwd[i] = fr_pow_u32(*omega, i); tw_inv[i] = fr_pow_u32(*omega_inv, i); }
+    if (i < n / 2) { tw_fwd[i] = to_fr29_image(fr_pow_u32(*omega, i)); tw_inv[i] = to_fr29_image(fr_pow_u32(*omega_inv, i)); }
     uint32_t br = __brev(i) >> (32 - L);
-    scale_mid[i] = Fr::mul(*n_inv, fr_pow_u32(*g, br));
+    {
+        fe9 c; for (int k = 0; k < 9; k++) c.l[k] = Fr29Q::FROM_R256(k);
+        const fe9 sm = Fr29::to_mont(Fr29::unpack(Fr::from_mont(Fr::mul(*n_inv, fr_pow_u32(*g, br)))));
+        scale_mid[i] = Fr29::pack(Fr29::freeze(Fr29::mul(sm, c)));
+    }
     scale_out[i] = Fr::from_mont(Fr::mul(*n_inv, fr_pow_u32(*g_inv, br)));
     if (i == 0) {
         fe gn = *g;
         for (int t = 0; t < L; t++) gn = Fr::sqr(gn);
-        *den_inv = Fr::inv(Fr::sub(gn, Fr::one()));
+        *den_inv = to_fr29_image(Fr::inv(Fr::sub(gn, Fr::one())));
     }
 }
 

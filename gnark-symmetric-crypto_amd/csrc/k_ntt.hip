@@ -15,26 +15,47 @@
 // Every kernel stages a tile of P proofs x 2^Lhi (or 2^Llo) elements in LDS, limb-major, one radix-2 stage
 // per barrier; global accesses are P*32 = 128-byte segments.
 #include "kernels.hpp"
+#include "bn254_fp29.hpp"
 
 namespace gsc {
 using namespace bn254;
 
 namespace {
 
-constexpr int P = 4;   // proofs per workgroup tile
+using F = Fr29;            // radix-2^29 lazy-limb scalar field (bn254_fp29.hpp): 227-instruction products, carry-free add/sub
+constexpr int P = 4;       // proofs per workgroup tile
+constexpr int32_t TOP2R = 6342812;     // top limb of 2r
+
+// Values inside the transforms are kept signed-tight (|limb| < 2^29) with value in (-r, 2r(1+1e-2)):
+// rng() brings a sum/difference of two such values back into that range using only the top limb (no comparison chain).
+__device__ __forceinline__ fe9 rng(const fe9& x) {
+    fe9 t = F::norm(x);
+    const bool hi = t.l[8] > TOP2R, lo = t.l[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.l[i] += hi ? -F::PK(1, i) : (lo ? F::PK(1, i) : 0);
+    return t;
+}
+// memory image between kernels: non-negative, tight, < 2^256 (not necessarily < r)
+__device__ __forceinline__ void store_lazy(fe* p, const fe9& x) {
+    fe9 t = F::norm(x);
+    const bool lo = t.l[8] < 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.l[i] += lo ? F::PK(0, i) : 0;
+    store_fe(p, F::pack(F::norm(t)));
+}
 
 struct Tile {
-    uint32_t* lds; uint32_t plane;   // plane = elements * P (words per limb plane)
-    __device__ __forceinline__ fe get(uint32_t e, uint32_t q) const {
-        fe r; const uint32_t o = e * P + q;
+    int32_t* lds; uint32_t plane;   // plane = elements * P (words per limb plane)
+    __device__ __forceinline__ fe9 get(uint32_t e, uint32_t q) const {
+        fe9 r; const uint32_t o = e * P + q;
 #pragma unroll
-        for (int i = 0; i < 8; i++) r.l[i] = lds[i * plane + o];
+        for (int i = 0; i < 9; i++) r.l[i] = lds[i * plane + o];
         return r;
     }
-    __device__ __forceinline__ void put(uint32_t e, uint32_t q, const fe& v) const {
+    __device__ __forceinline__ void put(uint32_t e, uint32_t q, const fe9& v) const {
         const uint32_t o = e * P + q;
 #pragma unroll
-        for (int i = 0; i < 8; i++) lds[i * plane + o] = v.l[i];
+        for (int i = 0; i < 9; i++) lds[i * plane + o] = v.l[i];
     }
 };
 
@@ -44,10 +65,10 @@ __device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q
     const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
     const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
     const uint32_t ex = (gi & (hg - 1)) << s;
-    fe u = t.get(e1, q), v = t.get(e2, q);
-    fe sum = Fr::add(u, v), dif = Fr::sub(u, v);
-    if (ex) dif = Fr::mul(dif, load_fe(tw + ex));
-    t.put(e1, q, sum); t.put(e2, q, dif);
+    const fe9 u = t.get(e1, q), v = t.get(e2, q);
+    const fe9 dif = F::sub(u, v);
+    t.put(e1, q, rng(F::add(u, v)));
+    t.put(e2, q, ex ? F::mul(dif, F::load(tw + ex)) : rng(dif));
 }
 // one DIT stage: half = 2^s; twiddle exponent = (gidx(e1) mod 2^s) << (L-1-s)
 template <bool STRIDED>
@@ -55,14 +76,17 @@ __device__ __forceinline__ void dit_stage(const Tile& t, uint32_t bf, uint32_t q
     const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
     const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
     const uint32_t ex = (gi & ((1u << s) - 1)) << (L - 1 - s);
-    fe u = t.get(e1, q), v = t.get(e2, q);
-    if (ex) v = Fr::mul(v, load_fe(tw + ex));
-    t.put(e1, q, Fr::add(u, v)); t.put(e2, q, Fr::sub(u, v));
+    const fe9 u = t.get(e1, q);
+    fe9 v = t.get(e2, q);
+    if (ex) v = F::mul(v, F::load(tw + ex));
+    t.put(e1, q, rng(F::add(u, v))); t.put(e2, q, rng(F::sub(u, v)));
 }
 
-// K1: strided DIF head.  grid (2^Llo, batch/P, nvec); block (2^(Lhi-1) * P)
+// K1: strided DIF head.  grid (2^Llo, batch/P, nvec); block (2^(Lhi-1) * P).  Input: the solver's a/b/c rows (canonical values of
+// the 2^256 Montgomery domain); they are used as they are — every stage is linear, and K2's scale table folds in the
+// change of domain (2^256 -> 2^261).
 __global__ void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, size_t batch) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t G = 1u << Lhi;
     fe* vec = blockIdx.z == 0 ? v0 : blockIdx.z == 1 ? v1 : v2;
@@ -71,8 +95,7 @@ __global__ void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, 
     Tile t{smem, G * P};
     for (uint32_t e = bf; e < G; e += G / 2) {
         const size_t idx = ((size_t)e << Llo) + g;
-        fe x = idx < m ? load_fe(vec + idx * batch + q0 + q) : Fr::zero();
-        t.put(e, q, x);
+        t.put(e, q, idx < m ? F::load(vec + idx * batch + q0 + q) : F::zero());
     }
     __syncthreads();
     for (int s = 0; s < Lhi; s++) {
@@ -82,13 +105,13 @@ __global__ void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, 
     }
     for (uint32_t e = bf; e < G; e += G / 2) {
         const size_t idx = ((size_t)e << Llo) + g;
-        store_fe(vec + idx * batch + q0 + q, t.get(e, q));
+        store_lazy(vec + idx * batch + q0 + q, t.get(e, q));
     }
 }
 
 // K2: contiguous DIF tail, coset scale, contiguous DIT head.  grid (2^Lhi, batch/P, nvec); block (2^(Llo-1) * P)
 __global__ void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batch) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t Cn = 1u << Llo;
     fe* vec = blockIdx.z == 0 ? v0 : blockIdx.z == 1 ? v1 : v2;
@@ -97,7 +120,7 @@ __global__ void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batc
     Tile t{smem, Cn * P};
     for (uint32_t e = bf; e < Cn; e += Cn / 2) {
         const size_t idx = ((size_t)b << Llo) + e;
-        t.put(e, q, load_fe(vec + idx * batch + q0 + q));
+        t.put(e, q, F::load(vec + idx * batch + q0 + q));
     }
     __syncthreads();
     for (int s = Lhi; s < L; s++) {
@@ -107,7 +130,7 @@ __global__ void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batc
     }
     for (uint32_t e = bf; e < Cn; e += Cn / 2) {
         const size_t idx = ((size_t)b << Llo) + e;
-        t.put(e, q, Fr::mul(t.get(e, q), load_fe(pl.scale_mid + idx)));
+        t.put(e, q, F::mul(t.get(e, q), F::load(pl.scale_mid + idx)));
     }
     __syncthreads();
     for (int s = 0; s < Llo; s++) {
@@ -116,24 +139,24 @@ __global__ void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batc
     }
     for (uint32_t e = bf; e < Cn; e += Cn / 2) {
         const size_t idx = ((size_t)b << Llo) + e;
-        store_fe(vec + idx * batch + q0 + q, t.get(e, q));
+        store_lazy(vec + idx * batch + q0 + q, t.get(e, q));
     }
 }
 
 // K3: strided DIT tail for a, b, c; h = (a*b - c) * den_inv; strided DIF head for h (written over a).
 __global__ void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const fe* vc, size_t batch) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t G = 1u << Lhi;
     const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
     const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
     Tile t{smem, G * P};
-    fe r1[3], r2[3];
+    fe9 r1[3], r2[3];
     for (int k = 0; k < 3; k++) {
         const fe* vec = k == 0 ? va : k == 1 ? vb : vc;
         for (uint32_t e = bf; e < G; e += G / 2) {
             const size_t idx = ((size_t)e << Llo) + g;
-            t.put(e, q, load_fe(vec + idx * batch + q0 + q));
+            t.put(e, q, F::load(vec + idx * batch + q0 + q));
         }
         __syncthreads();
         for (int s = Llo; s < L - 1; s++) {
@@ -142,23 +165,24 @@ __global__ void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const 
         }
         {   // last DIT stage (s = L-1): pairs (bf, bf + G/2), results stay in registers
             const uint32_t e1 = bf, e2 = bf + G / 2;
-            const uint32_t gi = (e1 << Llo) + g;
-            const uint32_t ex = gi & ((1u << (L - 1)) - 1);
-            fe u = t.get(e1, q), v = t.get(e2, q);
-            if (ex) v = Fr::mul(v, load_fe(pl.tw_fwd + ex));
-            r1[k] = Fr::add(u, v); r2[k] = Fr::sub(u, v);
+            const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
+            const fe9 u = t.get(e1, q);
+            fe9 v = t.get(e2, q);
+            if (ex) v = F::mul(v, F::load(pl.tw_fwd + ex));
+            const fe9 a1 = rng(F::add(u, v)), a2 = rng(F::sub(u, v));
+            if (k == 0) { r1[0] = a1; r2[0] = a2; } else if (k == 1) { r1[1] = a1; r2[1] = a2; } else { r1[2] = a1; r2[2] = a2; }
         }
         __syncthreads();
     }
-    const fe den = load_fe(pl.den_inv);
-    fe h1 = Fr::mul(Fr::sub(Fr::mul(r1[0], r1[1]), r1[2]), den);
-    fe h2 = Fr::mul(Fr::sub(Fr::mul(r2[0], r2[1]), r2[2]), den);
+    const fe9 den = F::load(pl.den_inv);
+    const fe9 h1 = F::mul(F::sub(F::mul(r1[0], r1[1]), r1[2]), den);     // (a*b - c) in (-3r, 4r): fine as a product operand
+    const fe9 h2 = F::mul(F::sub(F::mul(r2[0], r2[1]), r2[2]), den);
     {   // first DIF stage (s = 0): same pairs; twiddle exponent = gidx(e1) mod n/2
         const uint32_t e1 = bf, e2 = bf + G / 2;
         const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
-        fe sum = Fr::add(h1, h2), dif = Fr::sub(h1, h2);
-        if (ex) dif = Fr::mul(dif, load_fe(pl.tw_inv + ex));
-        t.put(e1, q, sum); t.put(e2, q, dif);
+        const fe9 dif = F::sub(h1, h2);
+        t.put(e1, q, rng(F::add(h1, h2)));
+        t.put(e2, q, ex ? F::mul(dif, F::load(pl.tw_inv + ex)) : rng(dif));
     }
     __syncthreads();
     for (int s = 1; s < Lhi; s++) {
@@ -168,13 +192,13 @@ __global__ void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const 
     }
     for (uint32_t e = bf; e < G; e += G / 2) {
         const size_t idx = ((size_t)e << Llo) + g;
-        store_fe(va + idx * batch + q0 + q, t.get(e, q));
+        store_lazy(va + idx * batch + q0 + q, t.get(e, q));
     }
 }
 
-// K4: contiguous DIF tail on h, then scale by n^-1 g^-j and leave Montgomery form.
+// K4: contiguous DIF tail on h, then scale by n^-1 g^-j and leave Montgomery form (canonical output in [0, r)).
 __global__ void k_ntt_final_contig(NttPlan pl, fe* vh, size_t batch) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t Cn = 1u << Llo;
     const uint32_t b = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
@@ -182,7 +206,7 @@ __global__ void k_ntt_final_contig(NttPlan pl, fe* vh, size_t batch) {
     Tile t{smem, Cn * P};
     for (uint32_t e = bf; e < Cn; e += Cn / 2) {
         const size_t idx = ((size_t)b << Llo) + e;
-        t.put(e, q, load_fe(vh + idx * batch + q0 + q));
+        t.put(e, q, F::load(vh + idx * batch + q0 + q));
     }
     __syncthreads();
     for (int s = Lhi; s < L; s++) {
@@ -192,7 +216,7 @@ __global__ void k_ntt_final_contig(NttPlan pl, fe* vh, size_t batch) {
     }
     for (uint32_t e = bf; e < Cn; e += Cn / 2) {
         const size_t idx = ((size_t)b << Llo) + e;
-        store_fe(vh + idx * batch + q0 + q, Fr::mul(t.get(e, q), load_fe(pl.scale_out + idx)));
+        F::store(vh + idx * batch + q0 + q, F::mul(t.get(e, q), F::load(pl.scale_out + idx)));
     }
 }
 
@@ -202,7 +226,11 @@ void launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t ba
     const int L = p.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const unsigned G = 1u << Lhi, Cn = 1u << Llo;
     const unsigned pb = (unsigned)(batch / P);
-    const size_t lds_s = (size_t)G * P * 32, lds_c = (size_t)Cn * P * 32;
+    const size_t lds_s = (size_t)G * P * 36, lds_c = (size_t)Cn * P * 36;      // nine 32-bit limb planes per element
+    if (lds_s > 65536) {       // 2^17 domains (AES-V2): 72 KiB tiles need the opt-in LDS limit (a CU has 160 KiB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_dif_strided), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pointwise_strided), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+    }
     hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, 3), dim3(G / 2 * P), lds_s, s, p, a, b, c, m, batch);
     hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 3), dim3(Cn / 2 * P), lds_c, s, p, a, b, c, batch);
     hipLaunchKernelGGL(k_ntt_pointwise_strided, dim3(Cn, pb, 1), dim3(G / 2 * P), lds_s, s, p, a, b, c, batch);
