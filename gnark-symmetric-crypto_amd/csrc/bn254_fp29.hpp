@@ -129,7 +129,61 @@ struct Field29 {
         r.l[8] = (int32_t)acc;
         return r;
     }
-    DEVFN static E sqr(const E& a) { return mul(a, a); }
+    // a^2 / 2^261: cross products taken once against the doubled operand (45 multiply-adds instead of 81).  a signed-tight.
+    DEVFN static E sqr(const E& a) {
+        int32_t m[9], a2[9]; E r; int64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) a2[i] = 2 * a.l[i];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; 2 * i < k; i++) acc += (int64_t)a.l[i] * a2[k - i];
+            if (k % 2 == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P(k - i);
+            m[k] = (int32_t)(((uint32_t)acc * NINV) & (uint32_t)MASK);
+            acc += (int64_t)m[k] * P(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; 2 * i < k; i++) acc += (int64_t)a.l[i] * a2[k - i];
+            if (k % 2 == 0) acc += (int64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (int64_t)m[i] * P(k - i);
+            r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
+            acc >>= 29;
+        }
+        r.l[8] = (int32_t)acc;
+        return r;
+    }
+    // (a*b - c*d) / 2^261 with ONE reduction: both products accumulate in the same columns (18 terms of < 2^58 plus the
+    // reduction terms stay below 2^63).  All four operands signed-tight.  Result tight, in (-1.6p, 2.6p).
+    DEVFN static E fmms(const E& a, const E& b, const E& c, const E& d) {
+        int32_t m[9]; E r; int64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) { acc += (int64_t)a.l[i] * b.l[k - i]; acc -= (int64_t)c.l[i] * d.l[k - i]; }
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P(k - i);
+            m[k] = (int32_t)(((uint32_t)acc * NINV) & (uint32_t)MASK);
+            acc += (int64_t)m[k] * P(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) { acc += (int64_t)a.l[i] * b.l[k - i]; acc -= (int64_t)c.l[i] * d.l[k - i]; }
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (int64_t)m[i] * P(k - i);
+            r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK);
+            acc >>= 29;
+        }
+        r.l[8] = (int32_t)acc;
+        return r;
+    }
     // canonical representative in [0, p), tight.  Input: value in (-8p, 24p), |limb| < 2^30.
     DEVFN static E freeze(const E& a) {
         E x;
@@ -236,6 +290,7 @@ struct Fp2x {
         const fe9 s = Fp29::norm(Fp29::add(a.a0, a.a1)), d = Fp29::norm(Fp29::sub(a.a0, a.a1));
         return E{Fp29::mul(s, d), Fp29::norm(Fp29::dbl(Fp29::mul(a.a0, a.a1)))};
     }
+    DEVFN static E fmms(const E& a, const E& b, const E& c, const E& d) { return norm(sub(mul(a, b), mul(c, d))); }
     DEVFN static E freeze(const E& a) { return E{Fp29::freeze(a.a0), Fp29::freeze(a.a1)}; }
     DEVFN static bool is_zero(const E& a) { return Fp29::is_zero(a.a0) && Fp29::is_zero(a.a1); }
     DEVFN static bool eq(const E& a, const E& b) { return is_zero(sub(a, b)); }
@@ -296,7 +351,7 @@ struct Curve9 {
         const E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(p.x, PP);
         X r; r.inf = false;
         r.x = F::norm(F::sub(F::sub(F::sqr(Rd), PPP), F::dbl(Q)));
-        r.y = F::norm(F::sub(F::mul(Rd, F::sub(Q, r.x)), F::mul(p.y, PPP)));
+        r.y = F::fmms(Rd, F::sub(Q, r.x), p.y, PPP);
         r.zz = F::mul(p.zz, PP);
         r.zzz = F::mul(p.zzz, PPP);
         return r;

@@ -88,7 +88,7 @@ class AlgorithmImpl {
     MsmSet<G1Aff> mA, mB1, mK, mZ, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
     // batch buffers
     size_t cap = 0;
-    DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts, d_h48; DevBuf<uint32_t> d_status; DevBuf<unsigned long long> d_dbg;
+    DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts, d_h48; DevBuf<uint32_t> d_status;
     DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
     DevBuf<fe> d_W, d_A, d_B, d_C;
     DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
@@ -249,7 +249,7 @@ class AlgorithmImpl {
 
     void alloc_batch(size_t B) {
         cap = B;
-        d_dbg.alloc(2); d_inputs.alloc(176 * B); d_rs.alloc(64 * B); d_out.alloc(256 * B); d_flags.alloc((B + 3) / 4 * 4); d_status.alloc(B);
+        d_inputs.alloc(176 * B); d_rs.alloc(64 * B); d_out.alloc(256 * B); d_flags.alloc((B + 3) / 4 * 4); d_status.alloc(B);
         d_W.alloc((n_wires + 4) * B); d_A.alloc(domain_n * B); d_B.alloc(domain_n * B); d_C.alloc(domain_n * B);
         size_t s1 = mA.nslices; for (size_t v : {mB1.nslices, mK.nslices, mZ.nslices, mPed.nslices}) if (v > s1) s1 = v;
         d_part1a.alloc(s1 * B); d_part1b.alloc((s1 + 63) / 64 * B);
@@ -318,8 +318,7 @@ class AlgorithmImpl {
         launch_prep_rs(d_rs.p, d_W.p, n_wires, B, has_commitment ? d_mask_in.p : nullptr, d_mask.p, stream);
         HIP_CHECK(hipMemsetAsync(d_status.p, 0xFF, B * 4, stream));
         SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p,
-                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, 0u, env_int("GSC_DBG", 0), d_dbg.p};
-        if (sa.dbg & 32) HIP_CHECK(hipMemsetAsync(d_dbg.p, 0, 16, stream));
+                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, 0u};
         auto run_levels = [&](uint32_t from, uint32_t to) {
             for (uint32_t l = from; l < to; l++) {
                 sa.first_level = l; sa.n_long = level_long[l];
@@ -343,8 +342,6 @@ class AlgorithmImpl {
             run_levels(commit_level, n_levels);
         } else run_levels(0, n_levels);
         HIP_CHECK(hipEventRecord(ev[1], stream));
-        if (sa.dbg & 32) { unsigned long long h[2]; HIP_CHECK(hipMemcpyAsync(h, d_dbg.p, 16, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream));
-            printf("solver wave0: %llu shader cycles, %llu x10ns -> %.0f MHz, %.1f us busy\n", h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[1] / 100.0); }
         if (dbg) {
             dbg->n_wires = n_wires; dbg->n_constraints = n_constraints; dbg->n = domain_n;
             fetch_column(d_W.p, n_wires, B, 0, dbg->W); fetch_column(d_A.p, n_constraints, B, 0, dbg->A);

@@ -52,16 +52,40 @@ __device__ __forceinline__ uint32_t bits_at(const fe& s, uint32_t pos, uint32_t 
     return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
+// raw memory image of one affine table entry (2 * WORDS field elements), kept packed until it is consumed
+template <class F> struct RawAff { fe w[2 * F::WORDS]; };
+template <class F> __device__ __forceinline__ RawAff<F> load_raw(const fe* p) {
+    RawAff<F> r;
+#pragma unroll
+    for (int i = 0; i < 2 * F::WORDS; i++) r.w[i] = load_fe(p + i);
+    return r;
+}
+__device__ __forceinline__ Aff9<Fp29f> unpack_aff(const RawAff<Fp29f>& r, bool negate) {
+    Aff9<Fp29f> e{Fp29::unpack(r.w[0]), Fp29::unpack(r.w[1])};
+    if (negate) e.y = Fp29::neg(e.y);                      // signed-tight: fine as a product operand
+    return e;
+}
+__device__ __forceinline__ Aff9<Fp2x> unpack_aff(const RawAff<Fp2x>& r, bool negate) {
+    Aff9<Fp2x> e{fe9x2{Fp29::unpack(r.w[0]), Fp29::unpack(r.w[1])}, fe9x2{Fp29::unpack(r.w[2]), Fp29::unpack(r.w[3])}};
+    if (negate) e.y = Fp2x::neg(e.y);
+    return e;
+}
+
 // One slice of bases for one proof (lane).  EXACT = false is the hot path (no degenerate-case tests inside madd).
+// Software pipelining: the table entry for the NEXT non-zero digit and the scalar of the NEXT base are requested before the
+// current mixed addition (~2 500 instructions) starts, so the 64-byte random HBM gathers are never on the critical path.
 template <class F, bool EXACT>
 __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0, size_t k1, size_t p) {
     using C = Curve9<F>;
     const uint32_t c = a.c, nwin = a.nwin, D = 1u << (c - 1);
     const fe* table = reinterpret_cast<const fe*>(a.table);
     Xyzz9<F> acc = C::infinity();
+    RawAff<F> pend; bool have = false, pend_neg = false;
+    auto scalar_of = [&](size_t k) { const size_t row = a.rows ? uni(a.rows[k]) : k; return load_fe(a.scalars + row * a.batch + p); };
+    fe s_next = k0 < k1 ? scalar_of(k0) : fe{};
     for (size_t k = k0; k < k1; k++) {
-        const size_t row = a.rows ? uni(a.rows[k]) : k;
-        fe s = load_fe(a.scalars + row * a.batch + p);
+        fe s = s_next;
+        if (k + 1 < k1) s_next = scalar_of(k + 1);
         if (a.scalars_mont) s = Fr::from_mont(s);
         const bool neg = sign_normalise(s);
         // number of windows this lane needs: highest set bit / c + 1 (+1 for a possible carry)
@@ -76,12 +100,13 @@ __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0
             bool dneg = false;
             if (raw > D) { raw = (1u << c) - raw; dneg = true; carry = 1; } else carry = 0;
             if (raw) {
-                Aff9<F> e = C::load_aff(table + (((size_t)k * nwin + j) * D + (raw - 1)) * (2 * F::WORDS));
-                if (dneg != neg) e.y = F::neg(e.y);           // signed-tight: fine as a product operand
-                acc = C::template madd<EXACT>(acc, e);
+                const RawAff<F> nxt = load_raw<F>(table + (((size_t)k * nwin + j) * D + (raw - 1)) * (2 * F::WORDS));
+                if (have) acc = C::template madd<EXACT>(acc, unpack_aff(pend, pend_neg));
+                pend = nxt; pend_neg = dneg != neg; have = true;
             }
         }
     }
+    if (have) acc = C::template madd<EXACT>(acc, unpack_aff(pend, pend_neg));
     return acc;
 }
 

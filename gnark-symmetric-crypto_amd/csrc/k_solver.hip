@@ -57,7 +57,7 @@ __device__ __forceinline__ uint32_t limb_at(const fe& v, uint32_t i) {
 // Code size matters here: every wave runs this straight-line path once, so instruction-cache misses dominate
 // if the body is unrolled (measured: 330 KB of code made a level take 170 us instead of ~20).
 // part / nparts: the chunks of the expression are dealt round-robin to `nparts` cooperating waves; the caller adds the partial sums.
-__device__ __forceinline__ fe eval_expr(Window& win, uint32_t at, const fe* coeff, const fe* W, size_t batch, size_t p, uint32_t& next, int dbg,
+__device__ __forceinline__ fe eval_expr(Window& win, uint32_t at, const fe* coeff, const fe* W, size_t batch, size_t p, uint32_t& next,
                                         uint32_t part = 0, uint32_t nparts = 1) {
     const uint32_t n = win.get(at);
     next = at + 1 + 2 * n;
@@ -81,15 +81,10 @@ __device__ __forceinline__ fe eval_expr(Window& win, uint32_t at, const fe* coef
             v[j] = load_fe(src);
             cfs[j] = load_fe(coeff + cidv[j]);
         }
-        if (dbg & 4) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) { v[j] = Fr::one(); cfs[j] = Fr::one(); }
-        }
         // Fold.  A lone wave issues one VALU instruction every ~9 cycles, so the per-term instruction count is what a long
         // expression (ChaCha's 130-term add32 rows) costs: the common cases are unrolled with static register indices;
         // only terms that really need a Montgomery product (general coefficient times a non-bit value) take the rolled path.
         uint32_t slow = 0;
-        if (dbg & 8) { acc = Fr::add(acc, v[0]); continue; }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (k0 + j < n) {
@@ -135,8 +130,6 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
     const bool coop = blockIdx.y < a.n_long;
     const uint32_t i = lstart[lev] + (coop ? blockIdx.y : a.n_long + (blockIdx.y - a.n_long) * WPB + wave);
     const uint32_t part = coop ? wave : 0u, nparts = coop ? (uint32_t)WPB : 1u, slot = coop ? 0u : wave;
-    const int dbg = a.dbg;
-    if (dbg & 1) return;
     if (i >= lstart[lev + 1]) return;          // only in wave-per-op workgroups, which never reach a barrier
     bool bad = false;
     Window win{a.prog, 0, 0, lane};
@@ -150,7 +143,7 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
 #pragma unroll 1
         for (uint32_t e = 0; e < nexpr; e++) {
             uint32_t next;
-            const fe r = eval_expr(win, q, a.coeff, a.W, batch, p, next, dbg, part, nparts);
+            const fe r = eval_expr(win, q, a.coeff, a.W, batch, p, next, part, nparts);
             q = next;
 #pragma unroll
             for (int k = 0; k < 8; k++) s_part[e][wave][k][lane] = r.l[k];       // own slot: no cross-wave hazard in wave-per-op mode
@@ -208,7 +201,7 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
 #pragma unroll 1
             for (uint32_t e = 0; e < nin; e++) {
                 uint32_t next;
-                const fe r = Fr::from_mont(eval_expr(win, q, a.coeff, a.W, batch, p, next, dbg));
+                const fe r = Fr::from_mont(eval_expr(win, q, a.coeff, a.W, batch, p, next));
                 q = next;
                 const uint32_t hi = r.l[1] | r.l[2] | r.l[3] | r.l[4] | r.l[5] | r.l[6] | r.l[7];
                 if (hi != 0 || r.l[0] >= 256) bad = true;
@@ -249,8 +242,8 @@ __global__ __launch_bounds__(64) void k_solver_count(SolverArgs a) {
 #pragma unroll 1
     for (uint32_t k = 0; k < nq; k++) {
         uint32_t next;
-        fe x0 = eval_expr(win, q, a.coeff, a.W, batch, p, next, 0); q = next;
-        fe x1 = eval_expr(win, q, a.coeff, a.W, batch, p, next, 0); q = next;
+        fe x0 = eval_expr(win, q, a.coeff, a.W, batch, p, next); q = next;
+        fe x1 = eval_expr(win, q, a.coeff, a.W, batch, p, next); q = next;
         const fe c0 = Fr::from_mont(x0);
         const uint32_t hi = c0.l[1] | c0.l[2] | c0.l[3] | c0.l[4] | c0.l[5] | c0.l[6] | c0.l[7];
         const bool in_range = hi == 0 && c0.l[0] < ntab;

@@ -52,8 +52,6 @@ struct SolverArgs {
     const fe* commit;                               // per proof commitment challenge (Montgomery) or nullptr
     int has_div;                                    // program contains divisions (R1C solved in L or R)
     uint32_t n_long;                                // the first n_long ops of the level get a whole workgroup each
-    int dbg;                                        // timing experiments only (GSC_DBG); 0 in production
-    unsigned long long* dbg_out;                    // [2]: shader-clock ticks, 100 MHz realtime ticks (dbg & 32)
 };
 // executes level a.first_level, which holds `level_width` instructions
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
