@@ -83,7 +83,7 @@ class AlgorithmImpl {
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
     uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; std::vector<uint32_t> level_long; int has_div = 0;
     // NTT
-    DevBuf<fe> tw_fwd, tw_inv, scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
+    DevBuf<int32_t> tw_fwd, tw_inv; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
     // MSM sets
     MsmSet<G1Aff> mA, mB1, mK, mZ, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
     // batch buffers
@@ -190,7 +190,7 @@ class AlgorithmImpl {
             DevBuf<uint8_t> d_be(sizeof be); d_be.upload(be, sizeof be, stream);
             dom.alloc(6);
             launch_fr_from_be(d_be.p, dom.p, 5, stream);
-            tw_fwd.alloc(domain_n / 2); tw_inv.alloc(domain_n / 2); scale_mid.alloc(domain_n); scale_out.alloc(domain_n);
+            tw_fwd.alloc(domain_n / 2 * 12); tw_inv.alloc(domain_n / 2 * 12); scale_mid.alloc(domain_n); scale_out.alloc(domain_n);
             launch_ntt_constants(dom.p, dom.p + 1, dom.p + 2, dom.p + 3, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, stream);
             HIP_CHECK(hipStreamSynchronize(stream));
         }

@@ -181,11 +181,15 @@ __device__ __forceinline__ fe fr_pow_u32(const fe& a, uint32_t e) {
 // last product of the pipeline leaves Montgomery form.
 __device__ __forceinline__ fe to_fr29_image(const fe& old_mont) { return Fr29::pack(Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(old_mont))))); }
 __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
-                                fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv) {
+                                int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 1u << L;
     if (i >= n) return;
-    if (i < n / 2) { tw_fwd[i] = to_fr29_image(fr_pow_u32(*omega, i)); tw_inv[i] = to_fr29_image(fr_pow_u32(*omega_inv, i)); }
+    if (i < n / 2) {      // twiddles are stored as limbs (12 int32 per entry), ready for the butterflies
+        const fe9 f = Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(fr_pow_u32(*omega, i)))));
+        const fe9 b = Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(fr_pow_u32(*omega_inv, i)))));
+        for (int k = 0; k < 12; k++) { tw_fwd[12 * (size_t)i + k] = k < 9 ? f.l[k] : 0; tw_inv[12 * (size_t)i + k] = k < 9 ? b.l[k] : 0; }
+    }
     uint32_t br = __brev(i) >> (32 - L);
     {
         fe9 c; for (int k = 0; k < 9; k++) c.l[k] = Fr29Q::FROM_R256(k);
@@ -225,7 +229,7 @@ void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c,
                                   reinterpret_cast<const Aff<Fp2>*>(bases), row0, nrows, c, nwin, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
 }
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
-                          fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s) {
+                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s) {
     size_t n = (size_t)1 << L;
     hipLaunchKernelGGL(k_ntt_constants, dim3(blocks_for(n, 64)), dim3(64), 0, s, omega, omega_inv, g, g_inv, n_inv, L,
                        tw_fwd, tw_inv, scale_mid, scale_out, den_inv);

@@ -44,6 +44,14 @@ __device__ __forceinline__ void store_lazy(fe* p, const fe9& x) {
     store_fe(p, F::pack(F::norm(t)));
 }
 
+// twiddles are stored already split into limbs: 12 int32 per entry (9 used; 48-byte stride keeps the three 16-byte loads aligned)
+__device__ __forceinline__ fe9 load_tw(const int32_t* tw, uint32_t ex) {
+    const int4* q = reinterpret_cast<const int4*>(tw + 12 * (size_t)ex);
+    const int4 a = q[0], b = q[1], c = q[2];
+    fe9 r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
+    return r;
+}
+
 struct Tile {
     int32_t* lds; uint32_t plane;   // plane = elements * P (words per limb plane)
     __device__ __forceinline__ fe9 get(uint32_t e, uint32_t q) const {
@@ -61,24 +69,24 @@ struct Tile {
 
 // one DIF stage on the tile: pairs (e1, e1 + he); twiddle exponent = (gidx(e1) mod hg) << s
 template <bool STRIDED>
-__device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, uint32_t hg, int s, int Llo, uint32_t tile_id, const fe* tw) {
+__device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, uint32_t hg, int s, int Llo, uint32_t tile_id, const int32_t* tw) {
     const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
     const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
     const uint32_t ex = (gi & (hg - 1)) << s;
     const fe9 u = t.get(e1, q), v = t.get(e2, q);
     const fe9 dif = F::sub(u, v);
     t.put(e1, q, rng(F::add(u, v)));
-    t.put(e2, q, ex ? F::mul(dif, F::load(tw + ex)) : rng(dif));
+    t.put(e2, q, ex ? F::mul(dif, load_tw(tw, ex)) : rng(dif));
 }
 // one DIT stage: half = 2^s; twiddle exponent = (gidx(e1) mod 2^s) << (L-1-s)
 template <bool STRIDED>
-__device__ __forceinline__ void dit_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, int s, int L, int Llo, uint32_t tile_id, const fe* tw) {
+__device__ __forceinline__ void dit_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, int s, int L, int Llo, uint32_t tile_id, const int32_t* tw) {
     const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
     const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
     const uint32_t ex = (gi & ((1u << s) - 1)) << (L - 1 - s);
     const fe9 u = t.get(e1, q);
     fe9 v = t.get(e2, q);
-    if (ex) v = F::mul(v, F::load(tw + ex));
+    if (ex) v = F::mul(v, load_tw(tw, ex));
     t.put(e1, q, rng(F::add(u, v))); t.put(e2, q, rng(F::sub(u, v)));
 }
 
@@ -168,7 +176,7 @@ __global__ void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const 
             const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
             const fe9 u = t.get(e1, q);
             fe9 v = t.get(e2, q);
-            if (ex) v = F::mul(v, F::load(pl.tw_fwd + ex));
+            if (ex) v = F::mul(v, load_tw(pl.tw_fwd, ex));
             const fe9 a1 = rng(F::add(u, v)), a2 = rng(F::sub(u, v));
             if (k == 0) { r1[0] = a1; r2[0] = a2; } else if (k == 1) { r1[1] = a1; r2[1] = a2; } else { r1[2] = a1; r2[2] = a2; }
         }
@@ -182,7 +190,7 @@ __global__ void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const 
         const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
         const fe9 dif = F::sub(h1, h2);
         t.put(e1, q, rng(F::add(h1, h2)));
-        t.put(e2, q, ex ? F::mul(dif, F::load(pl.tw_inv + ex)) : rng(dif));
+        t.put(e2, q, ex ? F::mul(dif, load_tw(pl.tw_inv, ex)) : rng(dif));
     }
     __syncthreads();
     for (int s = 1; s < Lhi; s++) {

@@ -31,7 +31,7 @@ void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c,
 // scale_mid[pos] = n^-1 * g^bitrev(pos) (Montgomery); scale_out[pos] = n^-1 * g^-bitrev(pos) (plain, so that the
 // Montgomery product with it leaves the result in canonical form).
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
-                          fe* tw_fwd, fe* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s);
+                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s);
 
 // ---- witness generation (k_solver.hip) ----
 // inputs: batch x 176 B records {key[32], nonce[12], counter u32 LE, pt[64], ct[64]} (ChaCha) laid out per proof.
@@ -61,7 +61,7 @@ void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStr
 void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s);
 
 // ---- quotient polynomial (k_ntt.hip) ----
-struct NttPlan { int L; const fe* tw_fwd; const fe* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* den_inv; };
+struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* den_inv; };   // tw_*: 12 int32 per entry (limbs)
 // a,b,c: [n][batch] Montgomery, first m rows valid (rows >= m are treated as zero and need not be initialised).
 // On return `a` holds h in canonical form: a[pos] = h_{bitrev(pos)} — the order pk.G1.Z is stored in.
 void launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s);
