@@ -31,6 +31,18 @@ def golden(name):
     return lzma.open(p + ".xz").read() if os.path.exists(p + ".xz") else open(p, "rb").read()
 
 
+def pmc_traffic(batch, engine_desc):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if they were taken
+    on this configuration; None otherwise (PMC counters cannot be collected from inside the timed run)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_msm_z_pmc.json")))
+        if d["config"]["batch"] == batch and ("window_z=%d " % d["config"]["window_z"]) in engine_desc:
+            return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def synthetic_records(n, seed):
     """n x 112 B {key[32], nonce[12], counter u32 LE, input[64]} — uniform bytes from a seeded generator."""
     import numpy as np
@@ -157,7 +169,7 @@ def main():
                                    "reference pk.chacha20/r1cs.chacha20, CSPRNG (r,s)" % B,
                        "batch_per_gpu": B, "parallelism": "proofs sharded over %d GPU(s), gather to rank 0" % world, "engine": g.describe(g.CHACHA20)},
             "roofline": {"kernel": "k_msm<Fp> (Z-table gather-accumulate)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(kb[-1], g.describe(g.CHACHA20)),
                          "launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
                          "whole_path_frac": round(value / world * BYTES_PER_PROOF / 1e9 / HBM_PEAK_GBS, 6)},
             "stage_ms_last_step": g.last_stage_ms(g.CHACHA20),
