@@ -9,6 +9,9 @@
 #include "host_ciphers.hpp"
 #include "json.hpp"
 #include <sys/random.h>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,8 +26,53 @@ namespace {
 
 const char* kAlgorithmNames[3] = {"chacha20", "aes-128-ctr", "aes-256-ctr"};   // prove_impl.go:21-25
 
+// Micro-batching: concurrent single-proof Prove() callers (the reference is called from many goroutines / FFI threads:
+// libraries/core_test.go:44-111) are gathered into ONE device batch instead of running one 25 ms proof each, back to back.
+// A worker thread per algorithm drains the queue: everything that arrived while the previous batch was on the GPU, plus
+// whatever arrives within a short linger window (GSC_LINGER_US, default 300 us), goes out together.
+class Batcher {
+  public:
+    explicit Batcher(Algorithm* a) : algo_(a) {
+        const char* e = getenv("GSC_LINGER_US"); linger_us_ = e && *e ? atoi(e) : 300;
+        worker_ = std::thread([this] { run(); });
+    }
+    ~Batcher() { { std::lock_guard<std::mutex> l(mu_); stop_ = true; } cv_.notify_all(); if (worker_.joinable()) worker_.join(); }
+    // blocks until the proof is done; throws std::runtime_error if the device batch failed
+    void submit(const ProofRequest& req, ProofResult& out) {
+        Item it{&req, &out, false, std::string()};
+        { std::unique_lock<std::mutex> l(mu_); q_.push_back(&it); cv_.notify_all(); done_cv_.wait(l, [&] { return it.done; }); }
+        if (!it.error.empty()) throw std::runtime_error(it.error);
+    }
+  private:
+    struct Item { const ProofRequest* req; ProofResult* res; bool done; std::string error; };
+    void run() {
+        for (;;) {
+            std::vector<Item*> take;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [&] { return stop_ || !q_.empty(); });
+                if (stop_ && q_.empty()) return;
+                if (linger_us_ > 0 && q_.size() < algo_->max_batch()) cv_.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return stop_ || q_.size() >= algo_->max_batch(); });
+                while (!q_.empty() && take.size() < algo_->max_batch()) { take.push_back(q_.front()); q_.pop_front(); }
+            }
+            std::vector<ProofRequest> reqs(take.size()); std::vector<ProofResult> res(take.size());
+            for (size_t i = 0; i < take.size(); i++) reqs[i] = *take[i]->req;
+            std::string err;
+            try { algo_->prove_batch(reqs.data(), reqs.size(), res.data()); } catch (const std::exception& e) { err = e.what(); }
+            {
+                std::lock_guard<std::mutex> l(mu_);
+                for (size_t i = 0; i < take.size(); i++) { *take[i]->res = res[i]; take[i]->error = err; take[i]->done = true; }
+            }
+            done_cv_.notify_all();
+        }
+    }
+    Algorithm* algo_; int linger_us_ = 300; bool stop_ = false;
+    std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Item*> q_; std::thread worker_;
+};
+
 std::mutex g_mu;
 std::unique_ptr<Algorithm> g_algo[3];
+std::unique_ptr<Batcher> g_batcher[3];     // declared after g_algo: destroyed first
 bool g_fixed_rand = false; uint8_t g_r[32], g_s[32], g_mask[32];   // little-endian canonical
 DebugVectors g_debug;
 
@@ -135,6 +183,7 @@ void fill_randomness(ProofRequest& q) {
 }
 
 Algorithm* lookup(int cipher) { std::lock_guard<std::mutex> l(g_mu); return g_algo[cipher].get(); }
+Batcher* batcher(int cipher) { std::lock_guard<std::mutex> l(g_mu); return g_batcher[cipher].get(); }
 
 std::string success_json(const ProofResult& r, const uint8_t ct[64]) {   // OutputParams, prove_impl.go:45-52
     return "{\"proof\":{\"proofJson\":\"" + base64_encode(r.proof, r.proof_len) + "\"},\"publicSignals\":\"" + base64_encode(ct, 64) + "\"}";
@@ -165,7 +214,8 @@ std::string prove_one_json(const char* data, size_t len, DebugVectors* dbg) {
         try { root = json_parse(data, len); } catch (const JsonSyntaxError& e) { throw GoPanic{"{\"Offset\":" + std::to_string(e.offset) + "}"}; }
         Prepared p = prepare(root);
         ProofResult res;
-        lookup(p.cipher)->prove_batch(&p.req, 1, &res, dbg);
+        if (dbg) lookup(p.cipher)->prove_batch(&p.req, 1, &res, dbg);      // test hook: straight to the device, keeps the intermediates
+        else batcher(p.cipher)->submit(p.req, res);                       // shares a device batch with concurrent callers
         if (res.status) throw GoPanic{"{}"};     // gnark solver / prover error: no exported fields
         return success_json(res, p.req.ciphertext);
     } catch (const GoPanic& g) {
@@ -191,6 +241,7 @@ GoUint8 InitAlgorithm(GoUint8 algorithmID, GoSlice provingKey, GoSlice r1cs) {
         if (!provingKey.data || provingKey.len <= 0 || !r1cs.data || r1cs.len <= 0) throw std::runtime_error("error reading proving key: EOF");
         g_algo[algorithmID].reset(new Algorithm((Cipher)algorithmID, (const uint8_t*)provingKey.data, (size_t)provingKey.len,
                                                 (const uint8_t*)r1cs.data, (size_t)r1cs.len, config_from_env()));
+        g_batcher[algorithmID].reset(new Batcher(g_algo[algorithmID].get()));
         return 1;
     } catch (const std::exception& e) {
         printf("%s\n", e.what());                                 // fmt.Println(err) in the reference

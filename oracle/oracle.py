@@ -24,6 +24,9 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        # the GPU boxes expose hundreds of hardware threads but give a process a share of ~16: do not let OpenMP oversubscribe and spin
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         L = C.CDLL(_LIB)
         vp, sz, u8p, u32, i32 = C.c_void_p, C.c_size_t, C.c_char_p, C.c_uint32, C.c_int
         L.orc_r1cs_new.restype = vp; L.orc_r1cs_new.argtypes = [u8p, sz]

@@ -140,3 +140,30 @@ def test_error_reporting_matches_reference_conventions(gsc_chacha):
     if aes_untouched:
         assert g.init_algorithm(g.AES_128, b"\x00" * 100, b"\x01" * 100) is False
         assert g.init_algorithm(g.AES_128, golden_bytes("pk.chacha20"), golden_bytes("r1cs.chacha20")) is False   # wrong circuit for the id
+
+
+def test_concurrent_prove_callers_share_device_batches(gsc_chacha, oracle, chacha_oracle):
+    # libraries/core_test.go:38-118 (TestProveVerify) calls Prove from several goroutines at once.  Here 96 threads call the
+    # C-ABI concurrently; the library gathers them into a few device batches, so the whole thing takes a fraction of 96
+    # sequential single proofs, and every answer still belongs to its own caller.
+    import threading
+    import time
+    g = gsc_chacha; _, _, vk = chacha_oracle
+    rnd = random.Random(4242)
+    n = 96
+    reqs = [_params(rnd.randbytes(32), rnd.randbytes(12), rnd.getrandbits(32), rnd.randbytes(64)) for _ in range(n)]
+    outs = [None] * n
+    t0 = time.time(); json.loads(g.prove(reqs[0])); single = time.time() - t0
+
+    def work(i):
+        outs[i] = json.loads(g.prove(reqs[i]))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    t0 = time.time()
+    for t in threads: t.start()
+    for t in threads: t.join()
+    elapsed = time.time() - t0
+    for q, out in zip(reqs, outs):
+        proof = base64.b64decode(out["proof"]["proofJson"]); ct = base64.b64decode(out["publicSignals"])
+        assert ct == oracle.chacha20_xor(bytes(q["key"]), bytes(q["nonce"]), q["counter"], bytes(q["input"]))
+        assert oracle.verify(vk, "chacha20", proof, _signals(ct, bytes(q["nonce"]), q["counter"], bytes(q["input"])))
+    assert elapsed < 0.25 * n * single, (elapsed, single)
