@@ -19,7 +19,7 @@ CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
 ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
 
 EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw",
-           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_msm_z_kernel_ms"]
+           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_msm_z_kernel_ms", "gsc_debug_field_ops"]
 
 
 class GoSlice(C.Structure):
@@ -64,6 +64,8 @@ def lib():
         L.gsc_last_stage_ms.argtypes = [C.c_ubyte, C.POINTER(C.c_float)]
         L.gsc_last_msm_z_kernel_ms.restype = C.c_float
         L.gsc_last_msm_z_kernel_ms.argtypes = [C.c_ubyte, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.gsc_debug_field_ops.restype = C.c_int
+        L.gsc_debug_field_ops.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int]
         L.enforce_binding()
         _lib = L
     return _lib
@@ -161,3 +163,13 @@ def last_msm_z_kernel(algorithm_id: int):
     b, nb = C.c_size_t(0), C.c_size_t(0)
     ms = lib().gsc_last_msm_z_kernel_ms(algorithm_id, C.byref(b), C.byref(nb))
     return float(ms), b.value, nb.value
+
+
+def debug_field_ops(field: int, op: int, a, b, chain=1):
+    """TEST HOOK: a, b lists of ints (canonical residues) -> list of ints computed by the device's radix-2^29 field code."""
+    n = len(a)
+    out = C.create_string_buffer(32 * n)
+    rc = lib().gsc_debug_field_ops(field, op, b"".join(int(x).to_bytes(32, "little") for x in a), b"".join(int(x).to_bytes(32, "little") for x in b), out, n, chain)
+    if rc:
+        raise RuntimeError("gsc_debug_field_ops failed")
+    return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(n)]

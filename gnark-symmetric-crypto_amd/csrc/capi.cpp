@@ -331,6 +331,11 @@ long long gsc_debug_vector(int which, uint8_t* out, size_t cap) {
     return (long long)(v->size() / 32);
 }
 
+int gsc_debug_field_ops(int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int chain) {
+    try { debug_field_ops(config_from_env().device, field, op, a, b, out, n, chain); return 0; }
+    catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
+}
+
 size_t gsc_describe(GoUint8 algorithmID, char* out, size_t cap) {
     if (algorithmID > 2 || !cap) return 0;
     Algorithm* a = lookup(algorithmID);

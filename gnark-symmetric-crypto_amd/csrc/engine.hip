@@ -410,6 +410,17 @@ class AlgorithmImpl {
     }
 };
 
+void debug_field_ops(int device, int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int chain) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available");
+    HIP_CHECK(hipSetDevice(device));
+    DevBuf<fe> da(n), db(n), dout(n);
+    HIP_CHECK(hipMemcpy(da.p, a, 32 * n, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(db.p, b, 32 * n, hipMemcpyHostToDevice));
+    launch_field_ops(field, op, da.p, db.p, dout.p, n, chain, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dout.p, 32 * n, hipMemcpyDeviceToHost));
+}
+
 Algorithm::Algorithm(Cipher cipher, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cfg)
     : impl_(new AlgorithmImpl(cipher, pk, pk_len, r1cs, r1cs_len, cfg)) {}
 Algorithm::~Algorithm() = default;

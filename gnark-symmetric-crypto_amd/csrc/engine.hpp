@@ -58,4 +58,8 @@ class Algorithm {
     std::unique_ptr<AlgorithmImpl> impl_;
 };
 
+// TEST HOOK: runs element-wise operations of the device's radix-2^29 field implementation (see kernels.hpp launch_field_ops).
+// a, b, out: n x 32 bytes little-endian canonical values (host memory).  Throws on HIP errors / missing GPU.
+void debug_field_ops(int device, int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int chain);
+
 }  // namespace gsc

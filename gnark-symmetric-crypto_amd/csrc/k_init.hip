@@ -204,6 +204,40 @@ __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* 
     }
 }
 
+// TEST HOOK kernel: element-wise field operations on canonical inputs, through the radix-2^29 implementation, canonical outputs.
+// op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inv, 5 fmms(a,b,b,a+... see host doc), 6 neg; lazy: apply the op `chain` times on a running value
+template <class F>
+__global__ void k_field_ops(int op, const fe* a, const fe* b, fe* out, size_t n, int chain) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fe9 x = F::to_mont(F::unpack(a[i])), y = F::to_mont(F::unpack(b[i]));
+    fe9 r = x;
+    for (int c = 0; c < chain; c++) {
+        switch (op) {
+            case 0: r = F::mul(r, y); break;
+            case 1: r = F::norm(F::add(r, y)); break;              // lazy sums: only carries are propagated between steps
+            case 2: r = F::norm(F::sub(r, y)); break;
+            case 3: r = F::sqr(r); break;
+            case 4: r = F::inv(r); break;
+            case 5: r = F::fmms(r, y, y, x); break;                // r*y - y*x
+            case 6: r = F::norm(F::neg(r)); break;
+            case 7: r = F::mul(F::sub(r, y), F::add(x, y)); break; // signed-tight x loose operands
+        }
+        if ((op == 1 || op == 2) && (c & 3) == 3) r = F::freeze(r);   // keep lazy chains inside freeze()'s documented domain
+    }
+    out[i] = F::pack(F::from_mont(r));
+}
+
+}  // namespace
+
+void launch_field_ops(int field, int op, const fe* a, const fe* b, fe* out, size_t n, int chain, hipStream_t s) {
+    if (!n) return;
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (field == 0) hipLaunchKernelGGL(k_field_ops<Fp29>, grid, block, 0, s, op, a, b, out, n, chain);
+    else hipLaunchKernelGGL(k_field_ops<Fr29>, grid, block, 0, s, op, a, b, out, n, chain);
+}
+
+namespace {
 }  // namespace
 
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }

@@ -33,6 +33,9 @@ void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c,
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
                           int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s);
 
+// TEST HOOK: radix-2^29 field self-test.  field 0 = Fp, 1 = Fr; a, b, out: n canonical 32-byte little-endian values (device memory).
+void launch_field_ops(int field, int op, const fe* a, const fe* b, fe* out, size_t n, int chain, hipStream_t s);
+
 // ---- witness generation (k_solver.hip) ----
 // inputs: batch x 176 B records {key[32], nonce[12], counter u32 LE, pt[64], ct[64]} (ChaCha) laid out per proof.
 // W layout: W[wire * batch + proof].

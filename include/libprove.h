@@ -63,6 +63,11 @@ extern void gsc_set_deterministic_randomness(const uint8_t *r_be32, const uint8_
 extern long long gsc_debug_prove(GoSlice params);
 extern long long gsc_debug_vector(int which, uint8_t *out, size_t cap);
 
+/* TEST HOOK: element-wise operations of the device's radix-2^29 field arithmetic, for unit tests against big integers.
+ * field: 0 = Fp, 1 = Fr.  op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inverse, 5 r*b - b*a (fused), 6 neg, 7 (r-b)*(a+b); the op is applied
+ * `chain` times to a running value r that starts at a.  a, b, out: n canonical 32-byte little-endian values.  0 on success. */
+extern int gsc_debug_field_ops(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int chain);
+
 /* Human-readable description of an initialised algorithm (sizes, table memory); returns bytes written. */
 extern size_t gsc_describe(GoUint8 algorithmID, char *out, size_t cap);
 /* Device milliseconds of the four stages (witness, quotient, msm, assembly) of the last batch of that algorithm. */
