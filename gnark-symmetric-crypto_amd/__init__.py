@@ -13,6 +13,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprove.so")
+VERIFY_LIB_PATH = os.path.join(_HERE, "libverify.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
@@ -173,3 +174,36 @@ def debug_field_ops(field: int, op: int, a, b, chain=1):
     if rc:
         raise RuntimeError("gsc_debug_field_ops failed")
     return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+
+
+# ---- libverify (CPU-side, libraries/verifier/libverify.go:14-17) ----
+_vlib = None
+
+
+def verify_lib():
+    global _vlib
+    if _vlib is None:
+        if not os.path.exists(VERIFY_LIB_PATH):
+            raise RuntimeError("libverify.so is not built: make -C %s" % CSRC)
+        L = C.CDLL(VERIFY_LIB_PATH)
+        L.Verify.restype = C.c_ubyte
+        L.Verify.argtypes = [GoSlice]
+        L.InitVerifier.restype = C.c_ubyte
+        L.InitVerifier.argtypes = [C.c_ubyte, GoSlice]
+        _vlib = L
+    return _vlib
+
+
+def init_verifier(algorithm_id: int, verifying_key: bytes) -> bool:
+    s, keep = _slice(verifying_key)
+    return bool(verify_lib().InitVerifier(algorithm_id, s))
+
+
+def verify(params) -> bool:
+    """Verify(params) — libverify.go:14-17.  params: bytes/str JSON or a dict with cipher / proof / publicSignals."""
+    if isinstance(params, dict):
+        params = json.dumps({k: (list(v) if isinstance(v, (bytes, bytearray)) else v) for k, v in params.items()})
+    if isinstance(params, str):
+        params = params.encode()
+    s, keep = _slice(params)
+    return bool(verify_lib().Verify(s))

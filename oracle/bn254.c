@@ -160,7 +160,10 @@ int g1_decode(g1aff *p, const uint8_t *b, size_t avail) {
     if (avail < 32) return -1;
     uint8_t flag = b[0] & 0xC0;
     uint8_t xb[32]; memcpy(xb, b, 32); xb[0] &= 0x3F;
-    if (flag == 0x40) { fp_set_zero(&p->x); fp_set_zero(&p->y); p->inf = 1; return 32; }
+    if (flag == 0x40) {   /* infinity: every other bit must be zero (gnark-crypto rejects anything else) */
+        for (int i = 0; i < 32; i++) if (xb[i]) return -1;
+        fp_set_zero(&p->x); fp_set_zero(&p->y); p->inf = 1; return 32;
+    }
     if (!fp_from_be(&p->x, xb)) return -1;
     p->inf = 0;
     if (flag == 0x00) {
@@ -179,7 +182,10 @@ int g2_decode(g2aff *p, const uint8_t *b, size_t avail) {
     if (avail < 64) return -1;
     uint8_t flag = b[0] & 0xC0;
     uint8_t xb[32]; memcpy(xb, b, 32); xb[0] &= 0x3F;
-    if (flag == 0x40) { fp2_set_zero(&p->x); fp2_set_zero(&p->y); p->inf = 1; return 64; }
+    if (flag == 0x40) {
+        for (int i = 0; i < 32; i++) if (xb[i] || b[32 + i]) return -1;
+        fp2_set_zero(&p->x); fp2_set_zero(&p->y); p->inf = 1; return 64;
+    }
     if (!fp_from_be(&p->x.a1, xb) || !fp_from_be(&p->x.a0, b + 32)) return -1;
     p->inf = 0;
     if (flag == 0x00) {
