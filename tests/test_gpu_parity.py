@@ -167,3 +167,15 @@ def test_concurrent_prove_callers_share_device_batches(gsc_chacha, oracle, chach
         assert ct == oracle.chacha20_xor(bytes(q["key"]), bytes(q["nonce"]), q["counter"], bytes(q["input"]))
         assert oracle.verify(vk, "chacha20", proof, _signals(ct, bytes(q["nonce"]), q["counter"], bytes(q["input"])))
     assert elapsed < 0.25 * n * single, (elapsed, single)
+
+
+def test_full_loop_through_both_drop_in_libraries_like_TestFullChaCha20(gsc_chacha):
+    # libraries/core_test.go:130-172 end to end: libprove.Prove -> libverify.Verify, nothing but the two C-ABIs
+    g = gsc_chacha
+    assert g.init_verifier(0, golden_bytes("vk.chacha20"))
+    rnd = random.Random(8)
+    key, nonce, pt, counter = rnd.randbytes(32), rnd.randbytes(12), rnd.randbytes(64), 1
+    out = json.loads(g.prove(_params(key, nonce, counter, pt)))
+    signals = base64.b64decode(out["publicSignals"]) + nonce + counter.to_bytes(4, "little") + pt
+    assert g.verify({"cipher": "chacha20", "proof": out["proof"]["proofJson"], "publicSignals": base64.b64encode(signals).decode()})
+    assert not g.verify({"cipher": "chacha20", "proof": out["proof"]["proofJson"], "publicSignals": base64.b64encode(signals[:-1] + b"\x00").decode()})
