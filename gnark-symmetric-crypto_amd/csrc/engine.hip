@@ -159,7 +159,7 @@ class AlgorithmImpl {
     }
 
     template <class AffT, class Decomp, class Build>
-    void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build) {
+    void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build, size_t bases_per_slice = 16) {
         const size_t n = raw.size() / point_bytes;
         if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
         DevBuf<AffT> bases(n ? n : 1);
@@ -169,7 +169,9 @@ class AlgorithmImpl {
             if (st[i] == 2) rows[i] = (uint32_t)(n_wires + 3);          // point at infinity: never selected
         }
         set.nbases = n; set.c = c; set.nwin = (254 + c - 1) / c;
-        set.nslices = (n + 63) / 64; if (!set.nslices) set.nslices = 1;
+        // Slices of few bases: the wire scalars are a mix of 0/1 and full-width values clustered by wire index, so a long slice
+        // full of wide scalars would be one wave's serial work for milliseconds while the rest of the chip idles (AES-V2).
+        set.nslices = (n + bases_per_slice - 1) / bases_per_slice; if (!set.nslices) set.nslices = 1;
         const size_t D = (size_t)1 << (c - 1);
         set.table.alloc(n * set.nwin * D ? n * set.nwin * D : 1);
         table_bytes += set.table.bytes();
@@ -234,11 +236,14 @@ class AlgorithmImpl {
             for (size_t r0 = 0; r0 < rows; r0 += chunk) launch_build_table_g2(b, r0, rows - r0 < chunk ? rows - r0 : chunk, c, nwin, t, scratch.p, stream);
             HIP_CHECK(hipStreamSynchronize(stream));
         };
-        build_set(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, bld1);
-        build_set(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, bld1);
-        build_set(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, bld1);
-        build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1);
-        build_set(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, bld2);
+        // wire MSMs: bit-only circuits (ChaCha) are uniform, so long slices are fine; circuits with lookups / commitments
+        // (AES-V2) carry clusters of full-width wires and want short slices (see build_set)
+        const size_t wps = cs.has_commitment ? 16 : 64;
+        build_set(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, bld1, wps);
+        build_set(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, bld1, wps);
+        build_set(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, bld1, wps);
+        build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1, 64);      // uniform full-width scalars
+        build_set(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, bld2, wps);
         if (cs.has_commitment) {
             if (cs.n_public_committed) throw std::runtime_error("r1cs: public committed wires are not supported");
             if (key.ped_basis.size() != cs.commit_private.size() * 32) throw std::runtime_error("pk: commitment basis size does not match the r1cs");
