@@ -106,7 +106,6 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ["GSC_DEVICE"] = str(local_rank)
     os.environ.setdefault("GSC_MAX_BATCH", str(args.batch))
-    os.environ.setdefault("GSC_WINDOW_Z", "13")       # 172 GB of Z digit tables: the bench configuration (library default is 12)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -118,7 +117,15 @@ def main():
 
     import gsc_loader
     g = gsc_loader.load()
-    if not g.init_algorithm(g.CHACHA20, golden("pk.chacha20"), golden("r1cs.chacha20")):
+    # Z digit tables: 13-bit digits (172 GB) is the bench configuration; fall back to narrower digits if this device cannot
+    # hold them (InitAlgorithm reports the failure and leaves the algorithm uninitialised, so it can simply be retried)
+    pk, r1cs = golden("pk.chacha20"), golden("r1cs.chacha20")
+    wanted = [os.environ["GSC_WINDOW_Z"]] if os.environ.get("GSC_WINDOW_Z") else ["13", "12", "11", "0"]
+    for wz in wanted:
+        os.environ["GSC_WINDOW_Z"] = wz
+        if g.init_algorithm(g.CHACHA20, pk, r1cs):
+            break
+    else:
         raise SystemExit("InitAlgorithm failed")
 
     B = args.batch
