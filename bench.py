@@ -121,12 +121,18 @@ def main():
     # hold them (InitAlgorithm reports the failure and leaves the algorithm uninitialised, so it can simply be retried)
     pk, r1cs = golden("pk.chacha20"), golden("r1cs.chacha20")
     wanted = [os.environ["GSC_WINDOW_Z"]] if os.environ.get("GSC_WINDOW_Z") else ["13", "12", "11", "0"]
-    for wz in wanted:
-        os.environ["GSC_WINDOW_Z"] = wz
-        if g.init_algorithm(g.CHACHA20, pk, r1cs):
-            break
-    else:
-        raise SystemExit("InitAlgorithm failed")
+    # the library reports errors on stdout like the reference (fmt.Println); keep this process' stdout for the one JSON line
+    sys.stdout.flush()
+    saved = os.dup(1); os.dup2(2, 1)
+    try:
+        for wz in wanted:
+            os.environ["GSC_WINDOW_Z"] = wz
+            if g.init_algorithm(g.CHACHA20, pk, r1cs):
+                break
+        else:
+            raise SystemExit("InitAlgorithm failed")
+    finally:
+        os.dup2(saved, 1); os.close(saved)
 
     B = args.batch
     dev = torch.device("cuda", local_rank)
