@@ -8,8 +8,8 @@
 //   * v_mad_u64_u32 is the workhorse: measured ~4.8 cycles / wave-instruction / SIMD, i.e. the same
 //     price as a carry-propagating 32-bit add (tools/ubench_intmul.hip, profiles/r01_ubench_intmul.txt).
 //   * No MFMA: 254-bit modular products are not a dense contraction.
-//   * Points: affine (x,y) for fixed bases / table entries, XYZZ (X, Y, ZZ, ZZZ) for accumulators:
-//     a mixed add is 8M + 2S with no inversion.
+//   * Used by the solver (values are mostly bits, the work is additions), the key-decompression kernels and wherever a
+//     value crosses an interface; the G1/G2 group law and the NTT run on the radix-2^29 field of bn254_fp29.hpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -234,78 +234,10 @@ struct Fp2 {
     DEVFN static bool lex_large(const E& a) { return Fp::is_zero(a.a1) ? Fp::lex_large(a.a0) : Fp::lex_large(a.a1); }
 };
 
-// ---- curve points, generic over the coordinate field F (Fp -> G1, Fp2 -> G2) ----
+// ---- affine point in this representation (what the key-decompression kernels produce); the group law itself lives in
+// bn254_fp29.hpp, on the radix-2^29 field ----
 template <class F>
-struct Aff { typename F::E x, y; };              // never the point at infinity (tables hold finite points)
-template <class F>
-struct Xyzz { typename F::E x, y, zz, zzz; };    // infinity <=> zz == 0
-
-template <class F>
-struct Curve {
-    using E = typename F::E;
-    using A = Aff<F>;
-    using X = Xyzz<F>;
-    DEVFN static X inf() { return X{F::zero(), F::zero(), F::zero(), F::zero()}; }
-    DEVFN static bool is_inf(const X& p) { return F::is_zero(p.zz); }
-    DEVFN static X from_aff(const A& a) { return X{a.x, a.y, F::one(), F::one()}; }
-    DEVFN static X dbl_slow(const X& p) { return dbl(p); }   // rare path; kept inline: a real call forces register spills around it
-    DEVFN static X dbl(const X& p) {
-        if (is_inf(p)) return p;
-        E U = F::dbl(p.y), V = F::sqr(U), Wv = F::mul(U, V), S = F::mul(p.x, V);
-        E xx = F::sqr(p.x), M = F::add(F::dbl(xx), xx);
-        X r;
-        r.x = F::sub(F::sqr(M), F::dbl(S));
-        r.y = F::sub(F::mul(M, F::sub(S, r.x)), F::mul(Wv, p.y));
-        r.zz = F::mul(V, p.zz);
-        r.zzz = F::mul(Wv, p.zzz);
-        return r;
-    }
-    // p + q, q affine (finite)
-    DEVFN static X madd(const X& p, const A& q) {
-        if (is_inf(p)) return from_aff(q);
-        E U2 = F::mul(q.x, p.zz), S2 = F::mul(q.y, p.zzz);
-        E Pd = F::sub(U2, p.x), Rd = F::sub(S2, p.y);
-        if (F::is_zero(Pd)) {   // rare: same x — doubling or cancellation (kept out of line)
-            if (F::is_zero(Rd)) return dbl_slow(from_aff(q));
-            return inf();
-        }
-        E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(p.x, PP);
-        X r;
-        r.x = F::sub(F::sub(F::sqr(Rd), PPP), F::dbl(Q));
-        r.y = F::sub(F::mul(Rd, F::sub(Q, r.x)), F::mul(p.y, PPP));
-        r.zz = F::mul(p.zz, PP);
-        r.zzz = F::mul(p.zzz, PPP);
-        return r;
-    }
-    DEVFN static X add(const X& p, const X& q) {
-        if (is_inf(p)) return q;
-        if (is_inf(q)) return p;
-        E U1 = F::mul(p.x, q.zz), U2 = F::mul(q.x, p.zz);
-        E S1 = F::mul(p.y, q.zzz), S2 = F::mul(q.y, p.zzz);
-        E Pd = F::sub(U2, U1), Rd = F::sub(S2, S1);
-        if (F::is_zero(Pd)) {
-            if (F::is_zero(Rd)) return dbl_slow(p);
-            return inf();
-        }
-        E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(U1, PP);
-        X r;
-        r.x = F::sub(F::sub(F::sqr(Rd), PPP), F::dbl(Q));
-        r.y = F::sub(F::mul(Rd, F::sub(Q, r.x)), F::mul(S1, PPP));
-        r.zz = F::mul(F::mul(p.zz, q.zz), PP);
-        r.zzz = F::mul(F::mul(p.zzz, q.zzz), PPP);
-        return r;
-    }
-    DEVFN static A neg(const A& a) { return A{a.x, F::neg(a.y)}; }
-    // to affine; caller guarantees !is_inf.  1/ZZ = ZZ^2 / ZZZ^2  (ZZ^3 = ZZZ^2)
-    DEVFN static A to_aff(const X& p) {
-        E i = F::inv(p.zzz);
-        E i2 = F::sqr(i);
-        E izz = F::mul(F::sqr(p.zz), i2);
-        return A{F::mul(p.x, izz), F::mul(p.y, i)};
-    }
-};
-using G1 = Curve<Fp>;
-using G2 = Curve<Fp2>;
+struct Aff { typename F::E x, y; };
 
 // ---- global-memory helpers: a field element is 32 B = two 16-B vector accesses ----
 DEVFN fe load_fe(const fe* p) {
