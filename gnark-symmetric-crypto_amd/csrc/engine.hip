@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 
 namespace gsc {
@@ -58,6 +61,8 @@ EngineConfig config_from_env() {
     EngineConfig c;
     c.device = env_int("GSC_DEVICE", 0);
     c.max_batch = (size_t)env_int("GSC_MAX_BATCH", 1024);
+    c.lanes = env_int("GSC_LANES", 1);
+    c.min_split = (size_t)env_int("GSC_MIN_SPLIT", 256);
     c.window_z = env_int("GSC_WINDOW_Z", 0);
     c.window_w = env_int("GSC_WINDOW_W", 0);
     c.z_table_gb = env_int("GSC_Z_TABLE_GB", 48);
@@ -74,9 +79,7 @@ class AlgorithmImpl {
     size_t n_wires = 0, n_public = 0, n_constraints = 0, domain_n = 0; int L = 0;
     bool has_commitment = false;
     std::mutex mu;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
-    float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
+    hipStream_t stream = nullptr;   // init-time work; proving runs on the lanes' streams
     size_t table_bytes = 0;
 
     // program
@@ -86,27 +89,42 @@ class AlgorithmImpl {
     DevBuf<int32_t> tw_fwd, tw_inv; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
     // MSM sets
     MsmSet<G1Aff> mA, mB1, mK, mZ, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
-    // batch buffers
-    size_t cap = 0;
-    DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts, d_h48; DevBuf<uint32_t> d_status;
-    DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
-    DevBuf<fe> d_W, d_A, d_B, d_C;
-    DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
+    // batch buffers: one set per lane.  A lane = a HIP stream with its own witness / polynomial / partial-sum buffers; with more than
+    // one lane big batches are cut into chunks that the lanes prove concurrently.  Measured on MI355X: two lanes do
+    // NOT beat one lane with the same number of proofs in flight (the MSM kernels already fill the chip and two of them thrash
+    // each other's table gathers), so the default is one lane; the option stays for hosts that prefer lower per-call latency.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
+        float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
+        size_t cap = 0;
+        DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts, d_h48; DevBuf<uint32_t> d_status;
+        DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
+        DevBuf<fe> d_W, d_A, d_B, d_C;
+        DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
+        ~Lane() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
+    };
+    std::vector<std::unique_ptr<Lane>> lanes;
+    size_t cap = 0;                     // proofs in flight over all lanes
 
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf) : cipher(c), cfg(cf) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the GPU prover has no CPU fallback");
         HIP_CHECK(hipSetDevice(cfg.device));
         HIP_CHECK(hipStreamCreate(&stream));
-        for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
         R1csFile cs = parse_r1cs(r1cs, r1cs_len);
         PkFile key = parse_pk(pk, pk_len);
         init_program(cs);
         init_key(cs, key);
-        alloc_batch(cfg.max_batch);
+        // lanes: GSC_LANES (default 1) as long as each keeps at least 64 proofs
+        size_t nl = (size_t)cfg.lanes; if (nl < 1) nl = 1;
+        while (nl > 1 && cfg.max_batch / nl < 64) nl--;
+        const size_t lane_cap = (cfg.max_batch / nl + 63) / 64 * 64;
+        for (size_t i = 0; i < nl; i++) { lanes.emplace_back(new Lane); alloc_lane(*lanes.back(), lane_cap); }
+        cap = lane_cap * nl;
         HIP_CHECK(hipStreamSynchronize(stream));
     }
-    ~AlgorithmImpl() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
+    ~AlgorithmImpl() { lanes.clear(); if (stream) (void)hipStreamDestroy(stream); }
 
     void init_program(const R1csFile& cs) {
         n_wires = cs.n_wires(); n_public = cs.n_public; n_constraints = cs.n_constraints; has_commitment = cs.has_commitment;
@@ -252,51 +270,67 @@ class AlgorithmImpl {
         }
     }
 
-    void alloc_batch(size_t B) {
-        cap = B;
-        d_inputs.alloc(176 * B); d_rs.alloc(64 * B); d_out.alloc(256 * B); d_flags.alloc((B + 3) / 4 * 4); d_status.alloc(B);
-        d_W.alloc((n_wires + 4) * B); d_A.alloc(domain_n * B); d_B.alloc(domain_n * B); d_C.alloc(domain_n * B);
-        size_t s1 = mA.nslices; for (size_t v : {mB1.nslices, mK.nslices, mZ.nslices, mPed.nslices}) if (v > s1) s1 = v;
-        d_part1a.alloc(s1 * B); d_part1b.alloc((s1 + 63) / 64 * B);
-        d_part2a.alloc(mB2.nslices * B); d_part2b.alloc((mB2.nslices + 63) / 64 * B);
-        d_sumA.alloc(B); d_sumB1.alloc(B); d_sumK.alloc(B); d_sumZ.alloc(B); d_sumB2.alloc(B); d_tmp.alloc(2 * B);
-        if (has_commitment) { d_mask_in.alloc(32 * B); d_mask.alloc(B); d_commit.alloc(B); d_cpts.alloc(128 * B); d_h48.alloc(48 * B); d_sumD.alloc(B); d_sumPok.alloc(B); }
+    void alloc_lane(Lane& ln, size_t B) {
+        ln.cap = B;
+        HIP_CHECK(hipStreamCreate(&ln.stream));
+        for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
+        ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B);
+        ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
+        // partial-sum buffers: the largest slices x batch product over every batch size this context can be asked for
+        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0;
+        for (size_t b = 64; b <= B; b += 64) {
+            for (const MsmSet<G1Aff>* m : {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}) { if (!m->nbases) continue; const size_t ns = slices_for(*m, b); if (ns * b > p1) p1 = ns * b; if ((ns + 63) / 64 * b > p1b) p1b = (ns + 63) / 64 * b; }
+            const size_t ns = slices_for(mB2, b); if (ns * b > p2) p2 = ns * b; if ((ns + 63) / 64 * b > p2b) p2b = (ns + 63) / 64 * b;
+        }
+        ln.d_part1a.alloc(p1); ln.d_part1b.alloc(p1b); ln.d_part2a.alloc(p2); ln.d_part2b.alloc(p2b);
+        ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
+        if (has_commitment) { ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_h48.alloc(48 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B); }
     }
 
-    void run_msm_g1(const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
-        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, set.nslices, d_part1a.p};
-        if (timed) HIP_CHECK(hipEventRecord(ev[5], stream));
-        launch_msm_g1(a, stream);
-        if (timed) HIP_CHECK(hipEventRecord(ev[6], stream));
-        G1Xyzz* src = d_part1a.p; G1Xyzz* alt = d_part1b.p; size_t ns = set.nslices;
+    // Slices per launch: the key's default (64 or 16 bases per slice) for big batches; for small batches more, shorter slices
+    // so that a single proof still spreads over the whole chip (~8k waves) instead of 512 long-running waves.
+    template <class S> static size_t slices_for(const S& set, size_t B) {
+        const size_t groups = B / 64, want = (8192 + groups - 1) / groups, most = (set.nbases + 3) / 4;
+        size_t n = set.nslices > want ? set.nslices : want;
+        if (n > most) n = most;
+        return n ? n : 1;
+    }
+    void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
+        const size_t nslices = slices_for(set, B);
+        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part1a.p};
+        if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
+        launch_msm_g1(a, ln.stream);
+        if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
+        G1Xyzz* src = ln.d_part1a.p; G1Xyzz* alt = ln.d_part1b.p; size_t ns = nslices;
         for (;;) {
             const size_t groups = (ns + 63) / 64;
             G1Xyzz* dst = groups == 1 ? sum : alt;
-            launch_msm_reduce_g1(src, ns, B, dst, stream);
+            launch_msm_reduce_g1(src, ns, B, dst, ln.stream);
             if (groups == 1) break;
             G1Xyzz* t = src; src = dst; alt = t; ns = groups;
         }
     }
-    void run_msm_g2(const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
-        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, set.nslices, d_part2a.p};
-        launch_msm_g2(a, stream);
-        G2Xyzz* src = d_part2a.p; G2Xyzz* alt = d_part2b.p; size_t ns = set.nslices;
+    void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
+        const size_t nslices = slices_for(set, B);
+        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part2a.p};
+        launch_msm_g2(a, ln.stream);
+        G2Xyzz* src = ln.d_part2a.p; G2Xyzz* alt = ln.d_part2b.p; size_t ns = nslices;
         for (;;) {
             const size_t groups = (ns + 63) / 64;
             G2Xyzz* dst = groups == 1 ? sum : alt;
-            launch_msm_reduce_g2(src, ns, B, dst, stream);
+            launch_msm_reduce_g2(src, ns, B, dst, ln.stream);
             if (groups == 1) break;
             G2Xyzz* t = src; src = dst; alt = t; ns = groups;
         }
     }
 
-    void fetch_column(const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
+    void fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
         out.resize(rows * 32);
-        HIP_CHECK(hipMemcpy2DAsync(out.data(), 32, reinterpret_cast<const uint8_t*>(mat) + 32 * col, B * 32, 32, rows, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpy2DAsync(out.data(), 32, reinterpret_cast<const uint8_t*>(mat) + 32 * col, B * 32, 32, rows, hipMemcpyDeviceToHost, ln.stream));
+        HIP_CHECK(hipStreamSynchronize(ln.stream));
     }
 
-    void prove_chunk(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg) {
+    void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg) {
         const size_t B = (n + 63) / 64 * 64;
         std::vector<uint8_t> h_in(176 * B), h_rs(64 * B);
         for (size_t i = 0; i < B; i++) {
@@ -308,26 +342,26 @@ class AlgorithmImpl {
             memcpy(rec + 48, q.plaintext, 64); memcpy(rec + 112, q.ciphertext, 64);
             memcpy(h_rs.data() + 64 * i, q.r, 32); memcpy(h_rs.data() + 64 * i + 32, q.s, 32);
         }
-        d_inputs.upload(h_in.data(), h_in.size(), stream);
-        d_rs.upload(h_rs.data(), h_rs.size(), stream);
-        HIP_CHECK(hipMemsetAsync(d_flags.p, 0, d_flags.bytes(), stream));
-        HIP_CHECK(hipEventRecord(ev[0], stream));
+        ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
+        ln.d_rs.upload(h_rs.data(), h_rs.size(), ln.stream);
+        HIP_CHECK(hipMemsetAsync(ln.d_flags.p, 0, ln.d_flags.bytes(), ln.stream));
+        HIP_CHECK(hipEventRecord(ln.ev[0], ln.stream));
         // 1. witness
-        if (cipher == CHACHA20) launch_assign_chacha(d_inputs.p, d_W.p, B, stream);
-        else launch_assign_aes(d_inputs.p, cipher == AES_128 ? 16 : 32, d_W.p, B, stream);
+        if (cipher == CHACHA20) launch_assign_chacha(ln.d_inputs.p, ln.d_W.p, B, ln.stream);
+        else launch_assign_aes(ln.d_inputs.p, cipher == AES_128 ? 16 : 32, ln.d_W.p, B, ln.stream);
         if (has_commitment) {
             std::vector<uint8_t> h_mask(32 * B);
             for (size_t i = 0; i < B; i++) memcpy(h_mask.data() + 32 * i, reqs[i < n ? i : n - 1].mask, 32);
-            d_mask_in.upload(h_mask.data(), h_mask.size(), stream);
+            ln.d_mask_in.upload(h_mask.data(), h_mask.size(), ln.stream);
         }
-        launch_prep_rs(d_rs.p, d_W.p, n_wires, B, has_commitment ? d_mask_in.p : nullptr, d_mask.p, stream);
-        HIP_CHECK(hipMemsetAsync(d_status.p, 0xFF, B * 4, stream));
-        SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p,
-                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, 0u};
+        launch_prep_rs(ln.d_rs.p, ln.d_W.p, n_wires, B, has_commitment ? ln.d_mask_in.p : nullptr, ln.d_mask.p, ln.stream);
+        HIP_CHECK(hipMemsetAsync(ln.d_status.p, 0xFF, B * 4, ln.stream));
+        SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p,
+                      has_commitment ? ln.d_mask.p : nullptr, has_commitment ? ln.d_commit.p : nullptr, has_div, 0u};
         auto run_levels = [&](uint32_t from, uint32_t to) {
             for (uint32_t l = from; l < to; l++) {
                 sa.first_level = l; sa.n_long = level_long[l];
-                if (level_kind[l]) launch_solver_count_level(sa, level_width[l], stream); else launch_solver_level(sa, level_width[l], stream);
+                if (level_kind[l]) launch_solver_count_level(sa, level_width[l], ln.stream); else launch_solver_level(sa, level_width[l], ln.stream);
             }
         };
         std::vector<uint8_t> h_cpts;
@@ -335,50 +369,50 @@ class AlgorithmImpl {
             // Groth16 commitment (gnark "BSB22"): solve up to the commitment hint, D = sum w_j * Basis_j over the
             // committed wires (same table MSM as everything else), challenge = hash_to_field(D uncompressed), resume.
             run_levels(0, commit_level);
-            run_msm_g1(mPed, d_W.p, 1, B, d_sumD.p);
-            launch_points_to_affine_be(d_sumD.p, B, d_cpts.p, d_flags.p, 8, stream);
+            run_msm_g1(ln, mPed, ln.d_W.p, 1, B, ln.d_sumD.p);
+            launch_points_to_affine_be(ln.d_sumD.p, B, ln.d_cpts.p, ln.d_flags.p, 8, ln.stream);
             h_cpts.resize(128 * B);
-            HIP_CHECK(hipMemcpyAsync(h_cpts.data(), d_cpts.p, 64 * B, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 64 * B, hipMemcpyDeviceToHost, ln.stream));
+            HIP_CHECK(hipStreamSynchronize(ln.stream));
             std::vector<uint8_t> h48(48 * B);
             for (size_t i = 0; i < B; i++) expand_message_xmd_sha256(h_cpts.data() + 64 * i, 64, "bsb22-commitment", h48.data() + 48 * i, 48);
-            d_h48.upload(h48.data(), h48.size(), stream);
-            launch_challenge_from_hash(d_h48.p, d_commit.p, B, stream);
+            ln.d_h48.upload(h48.data(), h48.size(), ln.stream);
+            launch_challenge_from_hash(ln.d_h48.p, ln.d_commit.p, B, ln.stream);
             run_levels(commit_level, n_levels);
         } else run_levels(0, n_levels);
-        HIP_CHECK(hipEventRecord(ev[1], stream));
+        HIP_CHECK(hipEventRecord(ln.ev[1], ln.stream));
         if (dbg) {
             dbg->n_wires = n_wires; dbg->n_constraints = n_constraints; dbg->n = domain_n;
-            fetch_column(d_W.p, n_wires, B, 0, dbg->W); fetch_column(d_A.p, n_constraints, B, 0, dbg->A);
-            fetch_column(d_B.p, n_constraints, B, 0, dbg->B); fetch_column(d_C.p, n_constraints, B, 0, dbg->C);
+            fetch_column(ln, ln.d_W.p, n_wires, B, 0, dbg->W); fetch_column(ln, ln.d_A.p, n_constraints, B, 0, dbg->A);
+            fetch_column(ln, ln.d_B.p, n_constraints, B, 0, dbg->B); fetch_column(ln, ln.d_C.p, n_constraints, B, 0, dbg->C);
         }
         // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
         NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5};
-        launch_compute_h(plan, d_A.p, d_B.p, d_C.p, n_constraints, B, stream);
-        HIP_CHECK(hipEventRecord(ev[2], stream));
-        if (dbg) fetch_column(d_A.p, domain_n, B, 0, dbg->H);
+        launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream);
+        HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
+        if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
         // 3. MSMs
-        run_msm_g1(mA, d_W.p, 1, B, d_sumA.p);
-        run_msm_g1(mB1, d_W.p, 1, B, d_sumB1.p);
-        run_msm_g2(mB2, d_W.p, 1, B, d_sumB2.p);
-        run_msm_g1(mK, d_W.p, 1, B, d_sumK.p);
-        run_msm_g1(mZ, d_A.p, 0, B, d_sumZ.p, true);
+        run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p);
+        run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p);
+        run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p);
+        run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
+        run_msm_g1(ln, mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, true);
         if (has_commitment) {      // proof of knowledge of the commitment: same scalars over sigma * Basis
-            run_msm_g1(mPedSigma, d_W.p, 1, B, d_sumPok.p);
-            launch_points_to_affine_be(d_sumPok.p, B, d_cpts.p + 64 * B, d_flags.p, 16, stream);
+            run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);
+            launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
         }
-        HIP_CHECK(hipEventRecord(ev[3], stream));
+        HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
         // 4. assembly
-        launch_finalize(d_sumA.p, d_sumB1.p, d_sumB2.p, d_sumK.p, d_sumZ.p, d_rs.p, B, d_out.p, d_flags.p, d_tmp.p, stream);
-        HIP_CHECK(hipEventRecord(ev[4], stream));
-        std::vector<uint8_t> h_out(256 * B), h_flags(d_flags.n); std::vector<uint32_t> h_status(B);
-        HIP_CHECK(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(h_flags.data(), d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, B * 4, hipMemcpyDeviceToHost, stream));
-        if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data() + 64 * B, d_cpts.p + 64 * B, 64 * B, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]); stage_ms[k] = ms; }
-        (void)hipEventElapsedTime(&msm_z_kernel_ms, ev[5], ev[6]); last_batch = B;
+        launch_finalize(ln.d_sumA.p, ln.d_sumB1.p, ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.stream);
+        HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
+        std::vector<uint8_t> h_out(256 * B), h_flags(ln.d_flags.n); std::vector<uint32_t> h_status(B);
+        HIP_CHECK(hipMemcpyAsync(h_out.data(), ln.d_out.p, h_out.size(), hipMemcpyDeviceToHost, ln.stream));
+        HIP_CHECK(hipMemcpyAsync(h_flags.data(), ln.d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, ln.stream));
+        HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
+        if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data() + 64 * B, ln.d_cpts.p + 64 * B, 64 * B, hipMemcpyDeviceToHost, ln.stream));
+        HIP_CHECK(hipStreamSynchronize(ln.stream));
+        for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
+        (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
         for (size_t i = 0; i < n; i++)
             serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts.data() + 64 * i : nullptr, has_commitment ? h_cpts.data() + 64 * B + 64 * i : nullptr, results[i]);
     }
@@ -431,22 +465,46 @@ Algorithm::Algorithm(Cipher cipher, const uint8_t* pk, size_t pk_len, const uint
 Algorithm::~Algorithm() = default;
 Cipher Algorithm::cipher() const { return impl_->cipher; }
 size_t Algorithm::max_batch() const { return impl_->cap; }
-void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impl_->stage_ms[i]; }
-float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impl_->last_batch; if (nbases) *nbases = impl_->mZ.nbases; return impl_->msm_z_kernel_ms; }
+void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impl_->lanes[0]->stage_ms[i]; }
+float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impl_->lanes[0]->last_batch; if (nbases) *nbases = impl_->mZ.nbases; return impl_->lanes[0]->msm_z_kernel_ms; }
 std::string Algorithm::describe() const {
     char buf[512];
-    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu",
-             impl_->n_wires, impl_->n_constraints, impl_->L, impl_->cap, impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
+    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu",
+             impl_->n_wires, impl_->n_constraints, impl_->L, impl_->cap, impl_->lanes.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
              impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases);
     return buf;
 }
 void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
     std::lock_guard<std::mutex> lock(impl_->mu);
-    HIP_CHECK(hipSetDevice(impl_->cfg.device));
-    for (size_t off = 0; off < n; off += impl_->cap) {
-        const size_t take = n - off < impl_->cap ? n - off : impl_->cap;
-        impl_->prove_chunk(reqs + off, take, results + off, off == 0 ? debug_first : nullptr);
-    }
+    AlgorithmImpl& a = *impl_;
+    if (!n) return;
+    // cut the request list into chunks (multiples of 64 proofs, at most one lane's capacity, at least two chunks per call when
+    // there are two lanes and enough work) and let every lane pull chunks until none are left
+    const size_t nl = a.lanes.size(), lane_cap = a.lanes[0]->cap;
+    size_t nchunks = (n + lane_cap - 1) / lane_cap;
+    if (nl > 1 && n >= 2 * a.cfg.min_split) { const size_t want = (nchunks + nl - 1) / nl * nl; nchunks = want; }
+    size_t chunk = ((n + nchunks - 1) / nchunks + 63) / 64 * 64;
+    if (chunk > lane_cap) chunk = lane_cap;
+    nchunks = (n + chunk - 1) / chunk;
+    std::atomic<size_t> next{0};
+    std::exception_ptr err; std::mutex err_mu;
+    auto work = [&](size_t li) {
+        try {
+            HIP_CHECK(hipSetDevice(a.cfg.device));
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= nchunks) break;
+                const size_t off = c * chunk, take = n - off < chunk ? n - off : chunk;
+                a.prove_chunk(*a.lanes[li], reqs + off, take, results + off, off == 0 ? debug_first : nullptr);
+            }
+        } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+    };
+    const size_t nthreads = nchunks < nl ? nchunks : nl;
+    std::vector<std::thread> th;
+    for (size_t li = 1; li < nthreads; li++) th.emplace_back(work, li);
+    work(0);
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
 }
 
 }  // namespace gsc

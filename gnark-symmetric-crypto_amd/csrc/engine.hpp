@@ -28,7 +28,9 @@ struct ProofResult {
 
 struct EngineConfig {
     int device = 0;
-    size_t max_batch = 1024;     // proofs in flight per launch sequence (rounded to a multiple of 64)
+    size_t max_batch = 1024;     // proofs in flight over all lanes (rounded to a multiple of 64 per lane)
+    int lanes = 1;               // concurrent HIP streams, each with its own batch buffers (GSC_LANES)
+    size_t min_split = 256;      // a call with at least 2*min_split proofs is spread over the lanes (GSC_MIN_SPLIT)
     int window_z = 0;            // digit width of the Z (quotient) tables; 0 = largest that fits z_table_gb (ChaCha: 12 -> 94 GB, 13 -> 172 GB; bench.py uses 13)
     int window_w = 0;            // digit width of the A / B1 / B2 / K / commitment tables; 0 = largest <= 8 that fits w_table_gb
     int z_table_gb = 48, w_table_gb = 24;   // per-algorithm HBM budgets used when the widths are not given

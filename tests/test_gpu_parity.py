@@ -4,6 +4,7 @@ CPU oracle on the same inputs, against the committed golden vectors, and through
 import base64
 import hashlib
 import json
+import os
 import random
 
 import pytest
@@ -179,3 +180,34 @@ def test_full_loop_through_both_drop_in_libraries_like_TestFullChaCha20(gsc_chac
     signals = base64.b64decode(out["publicSignals"]) + nonce + counter.to_bytes(4, "little") + pt
     assert g.verify({"cipher": "chacha20", "proof": out["proof"]["proofJson"], "publicSignals": base64.b64encode(signals).decode()})
     assert not g.verify({"cipher": "chacha20", "proof": out["proof"]["proofJson"], "publicSignals": base64.b64encode(signals[:-1] + b"\x00").decode()})
+
+
+_LANES_SCRIPT = r"""
+import hashlib, os, random, sys
+sys.path.insert(0, sys.argv[1])
+import gsc_loader
+from bench import golden as golden_bytes
+g = gsc_loader.load()
+assert g.init_algorithm(g.CHACHA20, golden_bytes("pk.chacha20"), golden_bytes("r1cs.chacha20"))
+assert "lanes=%s " % os.environ["GSC_LANES"] in g.describe(g.CHACHA20), g.describe(g.CHACHA20)
+rnd = random.Random(4242)
+n = 333
+recs = b"".join(rnd.randbytes(44) + rnd.getrandbits(32).to_bytes(4, "little") + rnd.randbytes(64) for _ in range(n))
+g.set_deterministic_randomness(rnd.getrandbits(250), rnd.getrandbits(250), 0)
+ok, proofs, lens, cts = g.prove_raw(g.CHACHA20, recs, n)
+assert ok == n
+print("DIGEST", hashlib.sha256(proofs + cts).hexdigest())
+"""
+
+
+def test_two_lanes_give_the_same_proofs_as_one():
+    # GSC_LANES is read at InitAlgorithm, so each configuration gets its own process (one at a time on the GPU).
+    import subprocess, sys
+    from conftest import ROOT
+    digests = []
+    for lanes in ("1", "2"):
+        env = dict(os.environ, GSC_LANES=lanes, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="8")
+        out = subprocess.run([sys.executable, "-c", _LANES_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
