@@ -86,7 +86,7 @@ class AlgorithmImpl {
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
     uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; std::vector<uint32_t> level_long; int has_div = 0;
     // NTT
-    DevBuf<int32_t> tw_fwd, tw_inv; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
+    DevBuf<int32_t> tw_fwd, tw_inv, qr; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
     // MSM sets
     MsmSet<G1Aff> mA, mB1, mK, mZ, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
     // batch buffers: one set per lane.  A lane = a HIP stream with its own witness / polynomial / partial-sum buffers; with more than
@@ -210,8 +210,8 @@ class AlgorithmImpl {
             DevBuf<uint8_t> d_be(sizeof be); d_be.upload(be, sizeof be, stream);
             dom.alloc(6);
             launch_fr_from_be(d_be.p, dom.p, 5, stream);
-            tw_fwd.alloc(domain_n / 2 * 12); tw_inv.alloc(domain_n / 2 * 12); scale_mid.alloc(domain_n); scale_out.alloc(domain_n);
-            launch_ntt_constants(dom.p, dom.p + 1, dom.p + 2, dom.p + 3, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, stream);
+            tw_fwd.alloc(domain_n / 2 * 12); tw_inv.alloc(domain_n / 2 * 12); scale_mid.alloc(domain_n); scale_out.alloc(domain_n); qr.alloc((2 * NTT_QMAX + 1) * 12);
+            launch_ntt_constants(dom.p, dom.p + 1, dom.p + 2, dom.p + 3, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, stream);
             HIP_CHECK(hipStreamSynchronize(stream));
         }
         auto cat = [](std::vector<uint8_t> a, std::initializer_list<const std::vector<uint8_t>*> more) { for (auto* m : more) a.insert(a.end(), m->begin(), m->end()); return a; };
@@ -387,7 +387,7 @@ class AlgorithmImpl {
             fetch_column(ln, ln.d_B.p, n_constraints, B, 0, dbg->B); fetch_column(ln, ln.d_C.p, n_constraints, B, 0, dbg->C);
         }
         // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
-        NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5};
+        NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
         launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream);
         HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
         if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);

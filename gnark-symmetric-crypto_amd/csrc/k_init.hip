@@ -181,9 +181,17 @@ __device__ __forceinline__ fe fr_pow_u32(const fe& a, uint32_t e) {
 // last product of the pipeline leaves Montgomery form.
 __device__ __forceinline__ fe to_fr29_image(const fe& old_mont) { return Fr29::pack(Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(old_mont))))); }
 __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
-                                int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv) {
+                                int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, int32_t* qr) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 1u << L;
+    if (i <= 2 * NTT_QMAX) {      // q*r, q = i - NTT_QMAX, as tight limbs with a signed top limb: the NTT kernels' range reduction subtracts these
+        const int64_t q = (int64_t)i - NTT_QMAX; int64_t acc = 0;
+        for (int k = 0; k < 12; k++) {
+            if (k < 9) acc += q * Fr29Q::PK(0, k);
+            qr[12 * (size_t)i + k] = k < 8 ? (int32_t)(acc & ((1 << 29) - 1)) : k == 8 ? (int32_t)acc : 0;
+            if (k < 8) acc >>= 29;
+        }
+    }
     if (i >= n) return;
     if (i < n / 2) {      // twiddles are stored as limbs (12 int32 per entry), ready for the butterflies
         const fe9 f = Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(fr_pow_u32(*omega, i)))));
@@ -263,10 +271,11 @@ void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c,
                                   reinterpret_cast<const Aff<Fp2>*>(bases), row0, nrows, c, nwin, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
 }
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
-                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, hipStream_t s) {
+                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, int32_t* qr, hipStream_t s) {
     size_t n = (size_t)1 << L;
+    if (n < 2 * NTT_QMAX + 1) n = 2 * NTT_QMAX + 1;
     hipLaunchKernelGGL(k_ntt_constants, dim3(blocks_for(n, 64)), dim3(64), 0, s, omega, omega_inv, g, g_inv, n_inv, L,
-                       tw_fwd, tw_inv, scale_mid, scale_out, den_inv);
+                       tw_fwd, tw_inv, scale_mid, scale_out, den_inv, qr);
 }
 
 }  // namespace gsc

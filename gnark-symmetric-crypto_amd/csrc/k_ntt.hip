@@ -24,23 +24,32 @@ namespace {
 
 using F = Fr29;            // radix-2^29 lazy-limb scalar field (bn254_fp29.hpp): 227-instruction products, carry-free add/sub
 constexpr int P = 4;       // proofs per workgroup tile
-constexpr int32_t TOP2R = 6342812;     // top limb of 2r
 
-// Values inside the transforms are kept signed-tight (|limb| < 2^29) with value in (-r, 2r(1+1e-2)):
-// rng() brings a sum/difference of two such values back into that range using only the top limb (no comparison chain).
-__device__ __forceinline__ fe9 rng(const fe9& x) {
-    fe9 t = F::norm(x);
-    const bool hi = t.l[8] > TOP2R, lo = t.l[8] < 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) t.l[i] += hi ? -F::PK(1, i) : (lo ? F::PK(1, i) : 0);
-    return t;
+// Ranges inside the transforms (Fr29: R' = 2^261 ~ 169 r, a product a*w with w < r lands in (-|a|/169, |a|/169 + r)):
+//   * limbs: everything written to a tile has |limb| < 2^30 (one lazy add/sub of tight values); an operand is carried
+//     (norm(), 24 instructions) only where it would otherwise meet a second lazy addition;
+//   * values: a DIT stage adds a fresh product to u, so |value| grows by <= 1.1 r per stage; a DIF stage doubles the
+//     sum path.  Instead of a comparison chain per butterfly, reduce_top() is applied once per DIF run of >= 4 stages
+//     and once before a kernel stores its tile: it estimates q = floor(value / r) from the top limb (float multiply)
+//     and subtracts the tabulated q*r, leaving a value in (-1.001 r, 2.001 r).
+constexpr float INV_TOP_R = 1.0f / 3171407.0f;     // top limb of r is 3171406
+__device__ __forceinline__ fe9 reduce_top(const fe9& x, const int32_t* qr) {
+    const fe9 t = F::norm(x);
+    int q = (int)floorf((float)t.l[8] * INV_TOP_R);
+    q = q < -NTT_QMAX ? -NTT_QMAX : (q > NTT_QMAX ? NTT_QMAX : q);
+    const int4* e = reinterpret_cast<const int4*>(qr + 12 * (q + NTT_QMAX));
+    const int4 a = e[0], b = e[1], c = e[2];
+    fe9 r;
+    r.l[0] = t.l[0] - a.x; r.l[1] = t.l[1] - a.y; r.l[2] = t.l[2] - a.z; r.l[3] = t.l[3] - a.w;
+    r.l[4] = t.l[4] - b.x; r.l[5] = t.l[5] - b.y; r.l[6] = t.l[6] - b.z; r.l[7] = t.l[7] - b.w; r.l[8] = t.l[8] - c.x;
+    return r;      // signed-tight
 }
 // memory image between kernels: non-negative, tight, < 2^256 (not necessarily < r)
-__device__ __forceinline__ void store_lazy(fe* p, const fe9& x) {
-    fe9 t = F::norm(x);
+__device__ __forceinline__ void store_lazy(fe* p, const fe9& x, const int32_t* qr) {
+    fe9 t = F::norm(reduce_top(x, qr));
     const bool lo = t.l[8] < 0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) t.l[i] += lo ? F::PK(0, i) : 0;
+    for (int i = 0; i < 9; i++) t.l[i] += lo ? F::PK(1, i) : 0;     // + 2r: (-1.001 r, 2.001 r) -> [0, 2.001 r)
     store_fe(p, F::pack(F::norm(t)));
 }
 
@@ -67,27 +76,40 @@ struct Tile {
     }
 };
 
-// one DIF stage on the tile: pairs (e1, e1 + he); twiddle exponent = (gidx(e1) mod hg) << s
-template <bool STRIDED>
-__device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, uint32_t hg, int s, int Llo, uint32_t tile_id, const int32_t* tw) {
+// one DIF stage on the tile: pairs (e1, e1 + he); twiddle exponent = (gidx(e1) mod hg) << s.  Operands in the tile are tight or
+// signed-tight (previous sums are carried before they are written); REDUCE additionally pulls the sum path back to (-r, 2r).
+template <bool STRIDED, bool REDUCE>
+__device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, uint32_t hg, int s, int Llo, uint32_t tile_id, const int32_t* tw, const int32_t* qr) {
     const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
     const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
     const uint32_t ex = (gi & (hg - 1)) << s;
     const fe9 u = t.get(e1, q), v = t.get(e2, q);
-    const fe9 dif = F::sub(u, v);
-    t.put(e1, q, rng(F::add(u, v)));
-    t.put(e2, q, ex ? F::mul(dif, load_tw(tw, ex)) : rng(dif));
+    const fe9 dif = F::sub(u, v), sum = F::add(u, v);
+    t.put(e1, q, REDUCE ? reduce_top(sum, qr) : F::norm(sum));
+    t.put(e2, q, ex ? F::mul(dif, load_tw(tw, ex)) : (REDUCE ? reduce_top(dif, qr) : F::norm(dif)));
 }
-// one DIT stage: half = 2^s; twiddle exponent = (gidx(e1) mod 2^s) << (L-1-s)
+// a run of DIF stages s0 .. s1-1 with one barrier per stage; the stage that completes four doublings reduces the sum path
+template <bool STRIDED>
+__device__ __forceinline__ void dif_run(const Tile& t, uint32_t bf, uint32_t q, int s0, int s1, int done, int L, int Llo, uint32_t tile_id, const NttPlan& pl) {
+    for (int s = s0; s < s1; s++) {
+        const uint32_t hg = 1u << (L - 1 - s);
+        const uint32_t he = STRIDED ? hg >> Llo : hg;
+        if (((s - s0 + done) & 3) == 3) dif_stage<STRIDED, true>(t, bf, q, he, hg, s, Llo, tile_id, pl.tw_inv, pl.qr);
+        else dif_stage<STRIDED, false>(t, bf, q, he, hg, s, Llo, tile_id, pl.tw_inv, pl.qr);
+        __syncthreads();
+    }
+}
+// one DIT stage: half = 2^s; twiddle exponent = (gidx(e1) mod 2^s) << (L-1-s).  u is carried, v (|limb| < 2^30) goes straight into
+// the product, so both results are again single lazy sums of tight values.
 template <bool STRIDED>
 __device__ __forceinline__ void dit_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, int s, int L, int Llo, uint32_t tile_id, const int32_t* tw) {
     const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
     const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
     const uint32_t ex = (gi & ((1u << s) - 1)) << (L - 1 - s);
-    const fe9 u = t.get(e1, q);
+    const fe9 u = F::norm(t.get(e1, q));
     fe9 v = t.get(e2, q);
-    if (ex) v = F::mul(v, load_tw(tw, ex));
-    t.put(e1, q, rng(F::add(u, v))); t.put(e2, q, rng(F::sub(u, v)));
+    v = ex ? F::mul(v, load_tw(tw, ex)) : F::norm(v);
+    t.put(e1, q, F::add(u, v)); t.put(e2, q, F::sub(u, v));
 }
 
 // K1: strided DIF head.  grid (2^Llo, batch/P, nvec); block (2^(Lhi-1) * P).  Input: the solver's a/b/c rows (canonical values of
@@ -106,14 +128,10 @@ __global__ void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, 
         t.put(e, q, idx < m ? F::load(vec + idx * batch + q0 + q) : F::zero());
     }
     __syncthreads();
-    for (int s = 0; s < Lhi; s++) {
-        const uint32_t hg = 1u << (L - 1 - s);
-        dif_stage<true>(t, bf, q, hg >> Llo, hg, s, Llo, g, pl.tw_inv);
-        __syncthreads();
-    }
+    dif_run<true>(t, bf, q, 0, Lhi, 0, L, Llo, g, pl);
     for (uint32_t e = bf; e < G; e += G / 2) {
         const size_t idx = ((size_t)e << Llo) + g;
-        store_lazy(vec + idx * batch + q0 + q, t.get(e, q));
+        store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
 }
 
@@ -131,11 +149,7 @@ __global__ void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batc
         t.put(e, q, F::load(vec + idx * batch + q0 + q));
     }
     __syncthreads();
-    for (int s = Lhi; s < L; s++) {
-        const uint32_t hg = 1u << (L - 1 - s);
-        dif_stage<false>(t, bf, q, hg, hg, s, Llo, b, pl.tw_inv);
-        __syncthreads();
-    }
+    dif_run<false>(t, bf, q, Lhi, L, 0, L, Llo, b, pl);
     for (uint32_t e = bf; e < Cn; e += Cn / 2) {
         const size_t idx = ((size_t)b << Llo) + e;
         t.put(e, q, F::mul(t.get(e, q), F::load(pl.scale_mid + idx)));
@@ -147,7 +161,7 @@ __global__ void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batc
     }
     for (uint32_t e = bf; e < Cn; e += Cn / 2) {
         const size_t idx = ((size_t)b << Llo) + e;
-        store_lazy(vec + idx * batch + q0 + q, t.get(e, q));
+        store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
 }
 
@@ -174,33 +188,29 @@ __global__ void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const 
         {   // last DIT stage (s = L-1): pairs (bf, bf + G/2), results stay in registers
             const uint32_t e1 = bf, e2 = bf + G / 2;
             const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
-            const fe9 u = t.get(e1, q);
+            const fe9 u = F::norm(t.get(e1, q));
             fe9 v = t.get(e2, q);
-            if (ex) v = F::mul(v, load_tw(pl.tw_fwd, ex));
-            const fe9 a1 = rng(F::add(u, v)), a2 = rng(F::sub(u, v));
+            v = ex ? F::mul(v, load_tw(pl.tw_fwd, ex)) : F::norm(v);
+            const fe9 a1 = F::norm(F::add(u, v)), a2 = F::norm(F::sub(u, v));      // tight; |value| <= 2^256/r + 8 * 1.1 < 15 r
             if (k == 0) { r1[0] = a1; r2[0] = a2; } else if (k == 1) { r1[1] = a1; r2[1] = a2; } else { r1[2] = a1; r2[2] = a2; }
         }
         __syncthreads();
     }
     const fe9 den = F::load(pl.den_inv);
-    const fe9 h1 = F::mul(F::sub(F::mul(r1[0], r1[1]), r1[2]), den);     // (a*b - c) in (-3r, 4r): fine as a product operand
+    const fe9 h1 = F::mul(F::sub(F::mul(r1[0], r1[1]), r1[2]), den);     // a*b in (-1.4r, 2.4r), minus c: |.| < 18 r, signed-tight: fine as a product operand
     const fe9 h2 = F::mul(F::sub(F::mul(r2[0], r2[1]), r2[2]), den);
     {   // first DIF stage (s = 0): same pairs; twiddle exponent = gidx(e1) mod n/2
         const uint32_t e1 = bf, e2 = bf + G / 2;
         const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
         const fe9 dif = F::sub(h1, h2);
-        t.put(e1, q, rng(F::add(h1, h2)));
-        t.put(e2, q, ex ? F::mul(dif, load_tw(pl.tw_inv, ex)) : rng(dif));
+        t.put(e1, q, F::norm(F::add(h1, h2)));
+        t.put(e2, q, ex ? F::mul(dif, load_tw(pl.tw_inv, ex)) : F::norm(dif));
     }
     __syncthreads();
-    for (int s = 1; s < Lhi; s++) {
-        const uint32_t hg = 1u << (L - 1 - s);
-        dif_stage<true>(t, bf, q, hg >> Llo, hg, s, Llo, g, pl.tw_inv);
-        __syncthreads();
-    }
+    dif_run<true>(t, bf, q, 1, Lhi, 1, L, Llo, g, pl);
     for (uint32_t e = bf; e < G; e += G / 2) {
         const size_t idx = ((size_t)e << Llo) + g;
-        store_lazy(va + idx * batch + q0 + q, t.get(e, q));
+        store_lazy(va + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
 }
 
@@ -217,11 +227,7 @@ __global__ void k_ntt_final_contig(NttPlan pl, fe* vh, size_t batch) {
         t.put(e, q, F::load(vh + idx * batch + q0 + q));
     }
     __syncthreads();
-    for (int s = Lhi; s < L; s++) {
-        const uint32_t hg = 1u << (L - 1 - s);
-        dif_stage<false>(t, bf, q, hg, hg, s, Llo, b, pl.tw_inv);
-        __syncthreads();
-    }
+    dif_run<false>(t, bf, q, Lhi, L, 0, L, Llo, b, pl);
     for (uint32_t e = bf; e < Cn; e += Cn / 2) {
         const size_t idx = ((size_t)b << Llo) + e;
         F::store(vh + idx * batch + q0 + q, F::mul(t.get(e, q), F::load(pl.scale_out + idx)));
