@@ -336,6 +336,15 @@ int gsc_debug_field_ops(int field, int op, const uint8_t* a, const uint8_t* b, u
     catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
 }
 
+long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t* abc_be, size_t m, uint8_t* h_out, size_t cap) {
+    if (algorithmID > 2) return -1;
+    Algorithm* a = lookup(algorithmID); if (!a) return -1;
+    if (!h_out) return (long long)a->domain_size();
+    if (cap < a->domain_size() * 64 * 32) return -1;
+    try { a->debug_compute_h(abc_be, m, h_out); return (long long)a->domain_size(); }
+    catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
+}
+
 size_t gsc_describe(GoUint8 algorithmID, char* out, size_t cap) {
     if (algorithmID > 2 || !cap) return 0;
     Algorithm* a = lookup(algorithmID);

@@ -474,6 +474,24 @@ std::string Algorithm::describe() const {
              impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases);
     return buf;
 }
+size_t Algorithm::domain_size() const { return impl_->domain_n; }
+void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out) {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    AlgorithmImpl& a = *impl_;
+    if (m > a.n_constraints) throw std::runtime_error("debug_compute_h: more rows than constraints");
+    HIP_CHECK(hipSetDevice(a.cfg.device));
+    AlgorithmImpl::Lane& ln = *a.lanes[0];
+    const size_t B = 64, cnt = m * B;
+    DevBuf<uint8_t> d_be(3 * cnt * 32 + 32);
+    d_be.upload(abc_be, 3 * cnt * 32, ln.stream);
+    launch_fr_from_be(d_be.p, ln.d_A.p, cnt, ln.stream);
+    launch_fr_from_be(d_be.p + cnt * 32, ln.d_B.p, cnt, ln.stream);
+    launch_fr_from_be(d_be.p + 2 * cnt * 32, ln.d_C.p, cnt, ln.stream);
+    NttPlan plan{a.L, a.tw_fwd.p, a.tw_inv.p, a.scale_mid.p, a.scale_out.p, a.dom.p + 5, a.qr.p};
+    launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, m, B, ln.stream);
+    HIP_CHECK(hipMemcpyAsync(h_out, ln.d_A.p, a.domain_n * B * 32, hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipStreamSynchronize(ln.stream));
+}
 void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
     std::lock_guard<std::mutex> lock(impl_->mu);
     AlgorithmImpl& a = *impl_;

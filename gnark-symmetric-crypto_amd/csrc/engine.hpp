@@ -56,6 +56,11 @@ class Algorithm {
     // HIP-event duration of the dominant kernel (k_msm<Fp> over the Z tables) in the last batch, the padded batch it ran on
     // and the number of bases it covered
     float last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const;
+    // TEST HOOK: the quotient kernels alone on caller-supplied vectors.  abc_be: three matrices [m][64] of canonical big-endian
+    // 32-byte values (a, then b, then c; 64 independent columns), m <= number of constraints.  h_out: [domain][64] 32-byte
+    // little-endian canonical values, row k = coefficient bitrev(k).
+    void debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out);
+    size_t domain_size() const;
   private:
     std::unique_ptr<AlgorithmImpl> impl_;
 };

@@ -68,6 +68,12 @@ extern long long gsc_debug_vector(int which, uint8_t *out, size_t cap);
  * `chain` times to a running value r that starts at a.  a, b, out: n canonical 32-byte little-endian values.  0 on success. */
 extern int gsc_debug_field_ops(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int chain);
 
+/* TEST HOOK: the quotient-polynomial kernels (computeH) alone, on caller-supplied vectors, 64 independent columns at once.
+ * abc_be: a, b, c one after the other, each [m][64] canonical big-endian 32-byte values (m <= constraints of the algorithm).
+ * h_out (cap bytes, at least domain*64*32): [domain][64] canonical little-endian values, row k = coefficient bitrev(k).
+ * Returns the domain size (also when h_out is NULL: size query), -1 on error. */
+extern long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t *abc_be, size_t m, uint8_t *h_out, size_t cap);
+
 /* Human-readable description of an initialised algorithm (sizes, table memory); returns bytes written. */
 extern size_t gsc_describe(GoUint8 algorithmID, char *out, size_t cap);
 /* Device milliseconds of the four stages (witness, quotient, msm, assembly) of the last batch of that algorithm. */

@@ -126,6 +126,19 @@ EXPORT int orc_verify(const void *vkp, int cipher, const uint8_t *proof, size_t 
     }
     return groth16_verify(vk, proof, proof_len, pub, np);
 }
+/* computeH alone on caller-supplied vectors (canonical big-endian, m <= domain size); h_be gets n elements, natural order.
+ * The vectors need not satisfy a*b = c: the pipeline of App. D is defined for any input. */
+EXPORT int orc_compute_h(const void *pkp, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *c_be, size_t m, uint8_t *h_be) {
+    const pk_t *pk = (const pk_t *)pkp;
+    if (m > pk->n) return -1;
+    fe *A = (fe *)malloc(sizeof(fe) * (m ? m : 1)), *B = (fe *)malloc(sizeof(fe) * (m ? m : 1)), *C = (fe *)malloc(sizeof(fe) * (m ? m : 1)), *h = (fe *)malloc(sizeof(fe) * pk->n);
+    int ok = 1;
+    for (size_t i = 0; i < m; i++) ok &= fr_from_be(&A[i], a_be + 32 * i) & fr_from_be(&B[i], b_be + 32 * i) & fr_from_be(&C[i], c_be + 32 * i);
+    if (ok) { compute_h(pk, A, B, C, m, h); for (size_t i = 0; i < pk->n; i++) fr_to_be(h_be + 32 * i, &h[i]); }
+    free(A); free(B); free(C); free(h);
+    return ok ? 0 : -2;
+}
+
 /* Setup with a seed; returns malloc'd key files (free with orc_free) */
 EXPORT int orc_setup(const void *csp, const uint8_t *seed32, uint8_t **pk, size_t *pk_len, uint8_t **vk, size_t *vk_len) {
     return groth16_setup((const r1cs_t *)csp, seed32, pk, pk_len, vk, vk_len);

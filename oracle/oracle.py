@@ -53,6 +53,7 @@ def lib():
         L.orc_setup.restype = i32
         L.orc_setup.argtypes = [vp, u8p, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
         L.orc_free.argtypes = [vp]
+        L.orc_compute_h.restype = i32; L.orc_compute_h.argtypes = [vp, u8p, u8p, u8p, sz, u8p]
         L.orc_pairing_selftest.restype = i32
         L.orc_field_const.argtypes = [i32, u8p]
         L.orc_init()
@@ -129,6 +130,15 @@ def prove(cs: R1CS, pk: ProvingKey, cipher, key, nonce, counter, pt, r=0, s=0, m
     if dump:
         return out.raw[: n.value], ct.raw, dict(zip("WABCh", [b.raw for b in bufs]))
     return out.raw[: n.value], ct.raw
+
+
+def compute_h(pk: ProvingKey, a_be: bytes, b_be: bytes, c_be: bytes) -> bytes:
+    """computeH on canonical big-endian vectors (len m*32 each) -> n*32 bytes, natural coefficient order."""
+    m = len(a_be) // 32
+    out = C.create_string_buffer(32 * pk.n)
+    if lib().orc_compute_h(pk.h, a_be, b_be, c_be, m, out):
+        raise RuntimeError("oracle compute_h failed")
+    return out.raw
 
 
 def verify(vk: VerifyingKey, cipher, proof: bytes, public_signals: bytes) -> bool:
