@@ -53,6 +53,8 @@ bool be_is_zero(const uint8_t* a) { for (int i = 0; i < 32; i++) if (a[i]) retur
 template <class AffT>
 struct MsmSet {                     // one fixed-base MSM: tables + scalar row map
     DevBuf<AffT> table; DevBuf<uint32_t> rows; size_t nbases = 0; int c = 0, nwin = 0; size_t nslices = 0;
+    // bases [0, nbit) are grouped in eights with subset-sum tables (kernels.hpp MsmArgs)
+    size_t nbit = 0; DevBuf<AffT> sub; DevBuf<uint8_t> group_ok;
 };
 
 }  // namespace
@@ -63,6 +65,7 @@ EngineConfig config_from_env() {
     c.max_batch = (size_t)env_int("GSC_MAX_BATCH", 1024);
     c.lanes = env_int("GSC_LANES", 1);
     c.min_split = (size_t)env_int("GSC_MIN_SPLIT", 256);
+    c.bit_groups = env_int("GSC_BIT_GROUPS", 1);
     c.window_z = env_int("GSC_WINDOW_Z", 0);
     c.window_w = env_int("GSC_WINDOW_W", 0);
     c.z_table_gb = env_int("GSC_Z_TABLE_GB", 48);
@@ -81,6 +84,7 @@ class AlgorithmImpl {
     std::mutex mu;
     hipStream_t stream = nullptr;   // init-time work; proving runs on the lanes' streams
     size_t table_bytes = 0;
+    std::vector<uint8_t> row_is_bit;   // per scalar row (wire): predicted to be 0 or 1 in every proof (calibrate_bits)
 
     // program
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
@@ -115,6 +119,7 @@ class AlgorithmImpl {
         R1csFile cs = parse_r1cs(r1cs, r1cs_len);
         PkFile key = parse_pk(pk, pk_len);
         init_program(cs);
+        calibrate_bits();
         init_key(cs, key);
         // lanes: GSC_LANES (default 1) as long as each keeps at least 64 proofs
         size_t nl = (size_t)cfg.lanes; if (nl < 1) nl = 1;
@@ -154,6 +159,75 @@ class AlgorithmImpl {
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
+    static void pack_inputs(const ProofRequest* reqs, size_t n, size_t B, std::vector<uint8_t>& h_in, std::vector<uint8_t>& h_rs) {
+        h_in.assign(176 * B, 0); h_rs.assign(64 * B, 0);
+        for (size_t i = 0; i < B; i++) {
+            const ProofRequest& q = reqs[i < n ? i : n - 1];
+            uint8_t* rec = h_in.data() + 176 * i;
+            memcpy(rec, q.key, q.keylen);
+            memcpy(rec + 32, q.nonce, 12);
+            rec[44] = (uint8_t)q.counter; rec[45] = (uint8_t)(q.counter >> 8); rec[46] = (uint8_t)(q.counter >> 16); rec[47] = (uint8_t)(q.counter >> 24);
+            memcpy(rec + 48, q.plaintext, 64); memcpy(rec + 112, q.ciphertext, 64);
+            memcpy(h_rs.data() + 64 * i, q.r, 32); memcpy(h_rs.data() + 64 * i + 32, q.s, 32);
+        }
+    }
+
+    // Which wires are bits?  Nothing in an R1CS says so, but it is a property of the circuit, not of the statement: solve 64
+    // pseudo-random statements once and call a wire a bit when it is 0 or 1 in all of them.  This is only a PREDICTION used to
+    // lay out the wire MSMs (bit wires first, in groups of eight with subset-sum tables); k_msm re-checks every group for
+    // every wave of proofs and falls back to the digit tables, so a wrong prediction costs time, never correctness.
+    void calibrate_bits() {
+        row_is_bit.assign(n_wires + 4, 0);
+        if (cfg.bit_groups <= 0) return;
+        if (cfg.bit_groups >= 2) { std::fill(row_is_bit.begin(), row_is_bit.begin() + n_wires, 1); return; }
+        const size_t B = 64;
+        std::vector<ProofRequest> reqs(B);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        auto next = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        for (auto& q : reqs) {
+            memset(&q, 0, sizeof q);
+            q.keylen = cipher == AES_128 ? 16 : 32;
+            for (uint32_t i = 0; i < q.keylen; i++) q.key[i] = (uint8_t)next();
+            for (auto& b : q.nonce) b = (uint8_t)next();
+            for (auto& b : q.plaintext) b = (uint8_t)next();
+            q.counter = (uint32_t)(next() & 0xFFFF);
+            if (cipher == CHACHA20) chacha20_xor_stream(q.key, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
+            else aes_ctr_xor_stream(q.key, q.keylen, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
+            q.r[0] = 3; q.s[0] = 5; q.mask[0] = 7;
+        }
+        std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs.data(), B, B, h_in, h_rs);
+        DevBuf<uint8_t> d_inputs(h_in.size()), d_rs(h_rs.size()), d_mask_in(32 * B); DevBuf<uint32_t> d_status(B);
+        DevBuf<fe> d_W((n_wires + 4) * B), d_A(n_constraints * B), d_B(n_constraints * B), d_C(n_constraints * B), d_mask(B), d_commit(B);
+        d_inputs.upload(h_in.data(), h_in.size(), stream); d_rs.upload(h_rs.data(), h_rs.size(), stream);
+        if (cipher == CHACHA20) launch_assign_chacha(d_inputs.p, d_W.p, B, stream);
+        else launch_assign_aes(d_inputs.p, cipher == AES_128 ? 16 : 32, d_W.p, B, stream);
+        HIP_CHECK(hipMemsetAsync(d_mask_in.p, 1, d_mask_in.bytes(), stream));
+        HIP_CHECK(hipMemsetAsync(d_commit.p, 1, d_commit.bytes(), stream));      // stands in for the commitment challenge: any residue will do
+        launch_prep_rs(d_rs.p, d_W.p, n_wires, B, has_commitment ? d_mask_in.p : nullptr, d_mask.p, stream);
+        HIP_CHECK(hipMemsetAsync(d_status.p, 0xFF, B * 4, stream));
+        SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p,
+                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, 0u};
+        for (uint32_t l = 0; l < n_levels; l++) {
+            sa.first_level = l; sa.n_long = level_long[l];
+            if (level_kind[l]) launch_solver_count_level(sa, level_width[l], stream); else launch_solver_level(sa, level_width[l], stream);
+        }
+        std::vector<uint32_t> h_W(n_wires * B * 8), h_status(B);
+        HIP_CHECK(hipMemcpyAsync(h_W.data(), d_W.p, n_wires * B * 32, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, B * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        static const uint32_t one[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};   // 2^256 mod r
+        for (size_t w = 0; w < n_wires; w++) {
+            bool bit = true;
+            for (size_t p = 0; p < B && bit; p++) {
+                if (h_status[p] != 0xFFFFFFFFu) continue;          // a statement the solver rejected says nothing
+                const uint32_t* v = h_W.data() + (w * B + p) * 8;
+                uint32_t z = 0, o = 0; for (int i = 0; i < 8; i++) { z |= v[i]; o |= v[i] ^ one[i]; }
+                bit = z == 0 || o == 0;
+            }
+            row_is_bit[w] = bit;
+        }
+    }
+
     // decompress `raw` (count points of `sz` bytes) into out[offset...]; returns per-point status
     std::vector<uint8_t> decompress_g1(const std::vector<uint8_t>& raw, G1Aff* out) {
         const size_t n = raw.size() / 32; std::vector<uint8_t> st(n);
@@ -177,9 +251,23 @@ class AlgorithmImpl {
     }
 
     template <class AffT, class Decomp, class Build>
-    void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build, size_t bases_per_slice = 16) {
+    void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build, size_t bases_per_slice = 16, bool wire_scalars = true) {
         const size_t n = raw.size() / point_bytes;
         if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
+        {   // bases whose scalars are predicted to be bits go first (stable order otherwise); the point at infinity never does
+            std::vector<size_t> order; order.reserve(n);
+            auto is_bit = [&](size_t i) { return wire_scalars && rows[i] < row_is_bit.size() && row_is_bit[rows[i]] && (raw[i * point_bytes] & 0xC0) != 0x40; };
+            for (size_t i = 0; i < n; i++) if (is_bit(i)) order.push_back(i);
+            set.nbit = order.size() / 8 * 8;
+            if (set.nbit) {
+                std::vector<uint8_t> taken(n, 0);
+                order.resize(set.nbit); for (size_t i : order) taken[i] = 1;
+                for (size_t i = 0; i < n; i++) if (!taken[i]) order.push_back(i);
+                std::vector<uint8_t> raw2(raw.size()); std::vector<uint32_t> rows2(n);
+                for (size_t j = 0; j < n; j++) { memcpy(raw2.data() + j * point_bytes, raw.data() + order[j] * point_bytes, point_bytes); rows2[j] = rows[order[j]]; }
+                raw.swap(raw2); rows.swap(rows2);
+            }
+        }
         DevBuf<AffT> bases(n ? n : 1);
         std::vector<uint8_t> st = decomp(raw, bases.p);
         for (size_t i = 0; i < n; i++) {
@@ -195,8 +283,16 @@ class AlgorithmImpl {
         table_bytes += set.table.bytes();
         set.rows.alloc(n ? n : 1); if (n) set.rows.upload(rows.data(), n, stream);
         build(bases.p, n, c, set.nwin, set.table.p);
+        if (set.nbit) {
+            const size_t ng = set.nbit / 8;
+            set.sub.alloc(ng * 255); set.group_ok.alloc(ng);
+            table_bytes += set.sub.bytes();
+            build_subset(bases.p, ng, set.sub.p, set.group_ok.p);
+        }
         HIP_CHECK(hipStreamSynchronize(stream));
     }
+    void build_subset(const G1Aff* b, size_t ng, G1Aff* t, uint8_t* ok) { DevBuf<G1Xyzz> sc(ng * 255); launch_build_subset_g1(b, ng, t, sc.p, ok, stream); HIP_CHECK(hipStreamSynchronize(stream)); }
+    void build_subset(const G2Aff* b, size_t ng, G2Aff* t, uint8_t* ok) { DevBuf<G2Xyzz> sc(ng * 255); launch_build_subset_g2(b, ng, t, sc.p, ok, stream); HIP_CHECK(hipStreamSynchronize(stream)); }
 
     void init_key(const R1csFile& cs, const PkFile& key) {
         if (key.n_wires != n_wires) throw std::runtime_error("pk: wire count does not match the r1cs");
@@ -260,7 +356,7 @@ class AlgorithmImpl {
         build_set(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, bld1, wps);
         build_set(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, bld1, wps);
         build_set(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, bld1, wps);
-        build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1, 64);      // uniform full-width scalars
+        build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1, 64, false);      // uniform full-width scalars
         build_set(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, bld2, wps);
         if (cs.has_commitment) {
             if (cs.n_public_committed) throw std::runtime_error("r1cs: public committed wires are not supported");
@@ -297,7 +393,7 @@ class AlgorithmImpl {
     }
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
         const size_t nslices = slices_for(set, B);
-        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part1a.p};
+        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part1a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p};
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
         launch_msm_g1(a, ln.stream);
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
@@ -312,7 +408,7 @@ class AlgorithmImpl {
     }
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
         const size_t nslices = slices_for(set, B);
-        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part2a.p};
+        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part2a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p};
         launch_msm_g2(a, ln.stream);
         G2Xyzz* src = ln.d_part2a.p; G2Xyzz* alt = ln.d_part2b.p; size_t ns = nslices;
         for (;;) {
@@ -332,16 +428,7 @@ class AlgorithmImpl {
 
     void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg) {
         const size_t B = (n + 63) / 64 * 64;
-        std::vector<uint8_t> h_in(176 * B), h_rs(64 * B);
-        for (size_t i = 0; i < B; i++) {
-            const ProofRequest& q = reqs[i < n ? i : n - 1];
-            uint8_t* rec = h_in.data() + 176 * i;
-            memset(rec, 0, 32); memcpy(rec, q.key, q.keylen);
-            memcpy(rec + 32, q.nonce, 12);
-            rec[44] = (uint8_t)q.counter; rec[45] = (uint8_t)(q.counter >> 8); rec[46] = (uint8_t)(q.counter >> 16); rec[47] = (uint8_t)(q.counter >> 24);
-            memcpy(rec + 48, q.plaintext, 64); memcpy(rec + 112, q.ciphertext, 64);
-            memcpy(h_rs.data() + 64 * i, q.r, 32); memcpy(h_rs.data() + 64 * i + 32, q.s, 32);
-        }
+        std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs, n, B, h_in, h_rs);
         ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
         ln.d_rs.upload(h_rs.data(), h_rs.size(), ln.stream);
         HIP_CHECK(hipMemsetAsync(ln.d_flags.p, 0, ln.d_flags.bytes(), ln.stream));

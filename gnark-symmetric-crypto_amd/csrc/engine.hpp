@@ -34,6 +34,7 @@ struct EngineConfig {
     int window_z = 0;            // digit width of the Z (quotient) tables; 0 = largest that fits z_table_gb (ChaCha: 12 -> 94 GB, 13 -> 172 GB; bench.py uses 13)
     int window_w = 0;            // digit width of the A / B1 / B2 / K / commitment tables; 0 = largest <= 8 that fits w_table_gb
     int z_table_gb = 48, w_table_gb = 24;   // per-algorithm HBM budgets used when the widths are not given
+    int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no subset tables; 1 for the wires a calibration witness predicts to be bits; 2 for every wire (test: exercises the fallback)
 };
 EngineConfig config_from_env();
 

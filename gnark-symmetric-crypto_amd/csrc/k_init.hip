@@ -167,6 +167,44 @@ __global__ void k_build_table(const Aff<OldF>* bases, size_t row0, size_t nrows,
     }
 }
 
+// Subset-sum tables for groups of eight bases whose scalars are bits in (almost) every proof: entry m-1 of group g is
+// sum_{b in m} P_{8g+b}, m = 1..255, affine.  One thread per group; the sums are built in XYZZ with the exact addition
+// (T[m] = T[m without its lowest bit] + P[lowest bit]), parked in `scratch` (255 points per group), and converted with one
+// batch inversion like k_build_table.  A group where some subset sums to the point at infinity (equal or opposite bases)
+// cannot be tabulated in affine form: ok[g] = 0 and the MSM kernel treats its bases one by one.
+template <class F, class OldF>
+__global__ void k_build_subset(const Aff<OldF>* bases, size_t ngroups, fe* table, fe* scratch, uint8_t* ok) {
+    using C = Curve9<F>;
+    using E = typename F::E;
+    constexpr int CW = F::WORDS;
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    fe* out = table + g * 255 * (2 * CW);
+    fe* sc = scratch + g * 255 * (4 * CW);
+    bool good = true;
+    E prefix = F::one();
+    for (uint32_t m = 1; m < 256; m++) {
+        const uint32_t low = (uint32_t)__ffs((int)m) - 1, rest = m & (m - 1);
+        const Aff9<F> P = base_to_fp29(bases + 8 * g + low);
+        Xyzz9<F> Em = rest ? C::template madd<true>(C::load_xyzz(sc + (rest - 1) * (4 * CW)), P) : C::from_aff(P);
+        if (Em.inf || F::is_zero(Em.zzz)) { good = false; Em = C::from_aff(P); }      // keep the arithmetic defined; the group is disabled
+        C::store_xyzz(sc + (m - 1) * (4 * CW), Em);
+        F::store(out + (m - 1) * (2 * CW), prefix);
+        prefix = F::mul(prefix, Em.zzz);
+    }
+    ok[g] = good ? 1 : 0;
+    E inv = F::inv(prefix);
+    for (uint32_t m = 255; m >= 1; m--) {
+        const Xyzz9<F> Em = C::load_xyzz(sc + (m - 1) * (4 * CW));
+        const E pre = F::load(out + (m - 1) * (2 * CW));
+        const E izzz = F::mul(inv, pre);
+        inv = F::mul(inv, Em.zzz);
+        const E izz = F::mul(F::sqr(Em.zz), F::sqr(izzz));
+        Aff9<F> a; a.x = F::mul(Em.x, izz); a.y = F::mul(Em.y, izzz);
+        C::store_aff(out + (m - 1) * (2 * CW), a);
+    }
+}
+
 __device__ __forceinline__ fe fr_pow_u32(const fe& a, uint32_t e) {
     fe acc = Fr::one(); bool started = false;
     for (int i = 31; i >= 0; i--) {
@@ -269,6 +307,14 @@ void launch_build_table_g1(const G1Aff* bases, size_t row0, size_t nrows, int c,
 void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c, int nwin, G2Aff* table, G2Xyzz* scratch, hipStream_t s) {
     if (nrows) hipLaunchKernelGGL((k_build_table<Fp2x, Fp2>), dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
                                   reinterpret_cast<const Aff<Fp2>*>(bases), row0, nrows, c, nwin, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
+}
+void launch_build_subset_g1(const G1Aff* bases, size_t ngroups, G1Aff* table, G1Xyzz* scratch, uint8_t* ok, hipStream_t s) {
+    if (ngroups) hipLaunchKernelGGL((k_build_subset<Fp29f, Fp>), dim3(blocks_for(ngroups, 64)), dim3(64), 0, s,
+                                    reinterpret_cast<const Aff<Fp>*>(bases), ngroups, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch), ok);
+}
+void launch_build_subset_g2(const G2Aff* bases, size_t ngroups, G2Aff* table, G2Xyzz* scratch, uint8_t* ok, hipStream_t s) {
+    if (ngroups) hipLaunchKernelGGL((k_build_subset<Fp2x, Fp2>), dim3(blocks_for(ngroups, 64)), dim3(64), 0, s,
+                                    reinterpret_cast<const Aff<Fp2>*>(bases), ngroups, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch), ok);
 }
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
                           int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, int32_t* qr, hipStream_t s) {

@@ -74,18 +74,54 @@ __device__ __forceinline__ Aff9<Fp2x> unpack_aff(const RawAff<Fp2x>& r, bool neg
 // One slice of bases for one proof (lane).  EXACT = false is the hot path (no degenerate-case tests inside madd).
 // Software pipelining: the table entry for the NEXT non-zero digit and the scalar of the NEXT base are requested before the
 // current mixed addition (~2 500 instructions) starts, so the 64-byte random HBM gathers are never on the critical path.
-template <class F, bool EXACT>
+//
+// Bit groups (bases below a.nbit): most wires of these circuits are bits, and lanes are different proofs, so a wave pays
+// one mixed addition per base as soon as a single proof has the bit set.  Eight such bases are taken together instead: the
+// eight scalars become a mask and ONE addition of the tabulated subset sum replaces up to eight.  The grouping is a
+// prediction made at InitAlgorithm; here every wave checks it (all 64 proofs, all eight scalars in {0, 1}) and otherwise
+// walks the eight bases through the digit tables like any other base, so results never depend on the prediction.
+template <class F, bool EXACT, bool BITS>
 __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0, size_t k1, size_t p) {
     using C = Curve9<F>;
     const uint32_t c = a.c, nwin = a.nwin, D = 1u << (c - 1);
     const fe* table = reinterpret_cast<const fe*>(a.table);
+    const fe* sub = reinterpret_cast<const fe*>(a.sub);
     Xyzz9<F> acc = C::infinity();
     RawAff<F> pend; bool have = false, pend_neg = false;
     auto scalar_of = [&](size_t k) { const size_t row = a.rows ? uni(a.rows[k]) : k; return load_fe(a.scalars + row * a.batch + p); };
-    fe s_next = k0 < k1 ? scalar_of(k0) : fe{};
-    for (size_t k = k0; k < k1; k++) {
-        fe s = s_next;
-        if (k + 1 < k1) s_next = scalar_of(k + 1);
+    size_t k = k0, single_until = 0;        // bases below single_until are walked one by one even inside the bit-group region
+    fe s_next = fe{}; bool have_next = false;
+    while (k < k1) {
+        if (BITS && k < a.nbit && k >= single_until) {      // wave-uniform: k is a multiple of 8 here
+            uint32_t mask = 0; bool ok = true;
+#pragma unroll 1
+            for (int h = 0; h < 8; h += 4) {        // four scalars in flight at a time: eight would cost a wave of occupancy
+                fe s4[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) s4[b] = scalar_of(k + h + b);
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    uint32_t z = 0, o = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { z |= s4[b].l[i]; o |= s4[b].l[i] ^ (a.scalars_mont ? FrParams::one(i) : (i == 0 ? 1u : 0u)); }
+                    ok = ok && (z == 0 || o == 0);
+                    mask |= (o == 0 ? 1u : 0u) << (h + b);
+                }
+            }
+            if (__all(ok) && uni(a.group_ok[k >> 3])) {
+                if (mask) {
+                    const RawAff<F> nxt = load_raw<F>(sub + ((k >> 3) * 255 + (mask - 1)) * (2 * F::WORDS));
+                    if (have) acc = C::template madd<EXACT>(acc, unpack_aff(pend, pend_neg));
+                    pend = nxt; pend_neg = false; have = true;
+                }
+                k += 8;
+                continue;
+            }
+            single_until = k + 8; have_next = false;
+        }
+        fe s = have_next ? s_next : scalar_of(k);
+        have_next = k + 1 < k1 && (!BITS || k + 1 >= a.nbit || k + 1 < single_until);
+        if (have_next) s_next = scalar_of(k + 1);
         if (a.scalars_mont) s = Fr::from_mont(s);
         const bool neg = sign_normalise(s);
         // number of windows this lane needs: highest set bit / c + 1 (+1 for a possible carry)
@@ -105,22 +141,24 @@ __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0
                 pend = nxt; pend_neg = dneg != neg; have = true;
             }
         }
+        k++;
     }
     if (have) acc = C::template madd<EXACT>(acc, unpack_aff(pend, pend_neg));
     return acc;
 }
 
-template <class F>
+// BITS = false is the instantiation for sets without bit groups (the Z tables: the dominant launch keeps its register budget)
+template <class F, bool BITS>
 __global__ __launch_bounds__(64) void k_msm(MsmArgs a) {
     using C = Curve9<F>;
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     const size_t slice = blockIdx.y;
-    const size_t per = (a.nbases + a.nslices - 1) / a.nslices;
-    const size_t k0 = slice * per, k1 = k0 + per < a.nbases ? k0 + per : a.nbases;
-    Xyzz9<F> acc = accumulate_slice<F, false>(a, k0, k1, p);
+    const size_t per = ((a.nbases + a.nslices - 1) / a.nslices + 7) & ~(size_t)7;      // bit groups never straddle slices
+    const size_t k0 = slice * per < a.nbases ? slice * per : a.nbases, k1 = k0 + per < a.nbases ? k0 + per : a.nbases;
+    Xyzz9<F> acc = accumulate_slice<F, false, BITS>(a, k0, k1, p);
     // A degenerate step (accumulator == +-entry) zeroes ZZ for good; it cannot be told from a genuine point at infinity
     // without the exact tests, so the (very rare) lane is recomputed with them.
-    if (!acc.inf && F::is_zero(acc.zz)) acc = accumulate_slice<F, true>(a, k0, k1, p);
+    if (!acc.inf && F::is_zero(acc.zz)) acc = accumulate_slice<F, true, BITS>(a, k0, k1, p);
     C::store_xyzz(reinterpret_cast<fe*>(a.partial) + (slice * a.batch + p) * (4 * F::WORDS), acc);
 }
 
@@ -229,10 +267,12 @@ __global__ void k_challenge_from_hash(const uint8_t* h48, fe* commit, size_t bat
 }  // namespace
 
 void launch_msm_g1(const MsmArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm<Fp29f>, dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
+    if (a.nbit) hipLaunchKernelGGL((k_msm<Fp29f, true>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_msm<Fp29f, false>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
 }
 void launch_msm_g2(const MsmArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm<Fp2x>, dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
+    if (a.nbit) hipLaunchKernelGGL((k_msm<Fp2x, true>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_msm<Fp2x, false>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
 }
 void launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s) {
     hipLaunchKernelGGL(k_msm_reduce<Fp29f>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,

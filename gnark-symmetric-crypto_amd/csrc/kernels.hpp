@@ -63,6 +63,9 @@ void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStr
 // *flag |= 1 if some OP_COUNT table's index column is not 0,1,2,... (InitAlgorithm-time validation)
 void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s);
 
+void launch_build_subset_g1(const G1Aff* bases, size_t ngroups, G1Aff* table, G1Xyzz* scratch, uint8_t* ok, hipStream_t s);
+void launch_build_subset_g2(const G2Aff* bases, size_t ngroups, G2Aff* table, G2Xyzz* scratch, uint8_t* ok, hipStream_t s);
+
 // ---- quotient polynomial (k_ntt.hip) ----
 struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* den_inv; const int32_t* qr; };   // tw_*, qr: 12 int32 per entry (limbs)
 constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_QMAX .. NTT_QMAX (range reduction by the top limb)
@@ -77,8 +80,11 @@ struct MsmArgs {
     const uint32_t* rows;          // scalar row per base (nullptr: row k)
     const fe* scalars;             // [row][batch]
     int scalars_mont;              // 1: Montgomery form, 0: canonical
-    size_t batch; size_t nslices;  // slices of ceil(nbases/nslices) consecutive bases
+    size_t batch; size_t nslices;  // slices of ceil(nbases/nslices) consecutive bases, rounded up to a multiple of 8
     void* partial;                 // G1Xyzz / G2Xyzz [nslices][batch]
+    // bit groups: bases [0, nbit) (nbit a multiple of 8) carry scalars that are 0 or 1 in nearly every proof; group g = bases
+    // 8g..8g+7 has a subset-sum table sub[g][m-1] = sum_{b in m} base_{8g+b} (255 affine entries) and group_ok[g] != 0
+    size_t nbit; const void* sub; const uint8_t* group_ok;
 };
 void launch_msm_g1(const MsmArgs& a, hipStream_t s);
 void launch_msm_g2(const MsmArgs& a, hipStream_t s);

@@ -182,32 +182,51 @@ def test_full_loop_through_both_drop_in_libraries_like_TestFullChaCha20(gsc_chac
     assert not g.verify({"cipher": "chacha20", "proof": out["proof"]["proofJson"], "publicSignals": base64.b64encode(signals[:-1] + b"\x00").decode()})
 
 
-_LANES_SCRIPT = r"""
+_OPTIONS_SCRIPT = r"""
 import hashlib, os, random, sys
 sys.path.insert(0, sys.argv[1])
 import gsc_loader
-from bench import golden as golden_bytes
+from bench import golden
 g = gsc_loader.load()
-assert g.init_algorithm(g.CHACHA20, golden_bytes("pk.chacha20"), golden_bytes("r1cs.chacha20"))
-assert "lanes=%s " % os.environ["GSC_LANES"] in g.describe(g.CHACHA20), g.describe(g.CHACHA20)
+algo = int(sys.argv[2])
+pk = open(sys.argv[3], "rb").read() if len(sys.argv) > 3 else golden("pk.chacha20")
+r1cs = golden(["r1cs.chacha20", "r1cs.aes128", "r1cs.aes256"][algo])
+assert g.init_algorithm(algo, pk, r1cs)
+assert "lanes=%s " % os.environ.get("GSC_LANES", "1") in g.describe(algo), g.describe(algo)
 rnd = random.Random(4242)
-n = 333
-recs = b"".join(rnd.randbytes(44) + rnd.getrandbits(32).to_bytes(4, "little") + rnd.randbytes(64) for _ in range(n))
-g.set_deterministic_randomness(rnd.getrandbits(250), rnd.getrandbits(250), 0)
-ok, proofs, lens, cts = g.prove_raw(g.CHACHA20, recs, n)
-assert ok == n
+n = 333 if algo == 0 else 70
+keylen = 16 if algo == 1 else 32
+recs = b"".join(rnd.randbytes(keylen) + bytes(32 - keylen) + rnd.randbytes(12) + rnd.getrandbits(16).to_bytes(4, "little") + rnd.randbytes(64) for _ in range(n))
+g.set_deterministic_randomness(rnd.getrandbits(250), rnd.getrandbits(250), rnd.getrandbits(250))
+ok, proofs, lens, cts = g.prove_raw(algo, recs, n)
+assert ok == n, ok
 print("DIGEST", hashlib.sha256(proofs + cts).hexdigest())
 """
 
 
-def test_two_lanes_give_the_same_proofs_as_one():
-    # GSC_LANES is read at InitAlgorithm, so each configuration gets its own process (one at a time on the GPU).
+def _digest(env_extra, algo=0, pk_path=None):
     import subprocess, sys
     from conftest import ROOT
-    digests = []
-    for lanes in ("1", "2"):
-        env = dict(os.environ, GSC_LANES=lanes, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="8")
-        out = subprocess.run([sys.executable, "-c", _LANES_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stdout + out.stderr
-        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0])
-    assert digests[0] == digests[1]
+    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="8", **env_extra)
+    args = [sys.executable, "-c", _OPTIONS_SCRIPT, ROOT, str(algo)] + ([pk_path] if pk_path else [])
+    out = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
+
+
+def test_engine_options_do_not_change_the_proofs():
+    # Options are read at InitAlgorithm, so each configuration gets its own process (one at a time on the GPU).  GSC_BIT_GROUPS=0
+    # never uses the subset-sum tables, =2 predicts EVERY wire to be a bit, so every group holding a wider value takes the
+    # in-kernel fallback; the default predicts from a calibration witness.  All must give byte-identical proofs.
+    base = _digest({})
+    for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}):
+        assert _digest(extra) == base, extra
+
+
+def test_engine_options_do_not_change_the_proofs_aes(aes_keys):
+    from conftest import ROOT
+    pk_path = os.path.join(ROOT, "build", "keys", "pk.aes128")
+    assert os.path.exists(pk_path)
+    base = _digest({}, 1, pk_path)
+    for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}):
+        assert _digest(extra, 1, pk_path) == base, extra
