@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSC_BENCH_BATCH", "4096")), help="proofs per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSC_BENCH_BATCH", "8192")), help="proofs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0)
     args = ap.parse_args()

@@ -151,8 +151,14 @@ __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0
 template <class F, bool BITS>
 __global__ __launch_bounds__(64) void k_msm(MsmArgs a) {
     using C = Curve9<F>;
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const size_t slice = blockIdx.y;
+    // XCD-aware order: workgroups go round-robin over the 8 XCDs by linear id, and each XCD has its own L2.  All proof groups of
+    // a slice read the same table rows, so they are placed on ONE XCD (consecutive ids there), not spread over all eight.
+    size_t slice = blockIdx.y, grp = blockIdx.x;
+    {
+        const size_t G = gridDim.x, L = (size_t)blockIdx.y * G + blockIdx.x, S8 = (size_t)gridDim.y & ~(size_t)7;
+        if (L < S8 * G) { const size_t xcd = L & 7, i = L >> 3; slice = (i / G) * 8 + xcd; grp = i % G; }
+    }
+    const size_t p = grp * 64 + threadIdx.x;
     const size_t per = ((a.nbases + a.nslices - 1) / a.nslices + 7) & ~(size_t)7;      // bit groups never straddle slices
     const size_t k0 = slice * per < a.nbases ? slice * per : a.nbases, k1 = k0 + per < a.nbases ? k0 + per : a.nbases;
     Xyzz9<F> acc = accumulate_slice<F, false, BITS>(a, k0, k1, p);
