@@ -7,7 +7,7 @@ Prove; no JSON on the timed path).  Independent proofs shard across ranks (one p
 scaling); the only collective is the gather of the finished proofs to rank 0 (RCCL over xGMI).
 
 Prints ONE JSON line on rank 0 (see the harness contract): metric/value/unit..., plus
-  "roofline"      : the dominant kernel (k_msm<Fp29f> over the Z digit tables) priced against HBM peak, timed live with HIP events;
+  "roofline"      : the dominant kernel (k_msm<Fp29f,false> over the Z digit tables) priced against HBM peak, timed live with HIP events;
   "cpu_baseline"  : the CPU oracle (oracle/, a port — not gnark) timed on the host cores on a bounded sample.
 """
 import argparse
@@ -181,7 +181,7 @@ def main():
             "config": {"workload": "ChaCha20-V3 single 64-byte block, 1xMI355X per rank: batch of %d independent proofs per GPU per step, "
                                    "reference pk.chacha20/r1cs.chacha20, CSPRNG (r,s)" % B,
                        "batch_per_gpu": B, "parallelism": "proofs sharded over %d GPU(s), gather to rank 0" % world, "engine": g.describe(g.CHACHA20)},
-            "roofline": {"kernel": "k_msm<Fp29f> (Z-table gather-accumulate)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "k_msm<Fp29f,false> (Z-table gather-accumulate)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(kb[-1], g.describe(g.CHACHA20)),
                          "launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
                          "whole_path_frac": round(value / world * BYTES_PER_PROOF / 1e9 / HBM_PEAK_GBS, 6)},
