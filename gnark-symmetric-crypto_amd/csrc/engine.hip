@@ -375,8 +375,8 @@ class AlgorithmImpl {
         // partial-sum buffers: the largest slices x batch product over every batch size this context can be asked for
         size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0;
         for (size_t b = 64; b <= B; b += 64) {
-            for (const MsmSet<G1Aff>* m : {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}) { if (!m->nbases) continue; const size_t ns = slices_for(*m, b); if (ns * b > p1) p1 = ns * b; if ((ns + 63) / 64 * b > p1b) p1b = (ns + 63) / 64 * b; }
-            const size_t ns = slices_for(mB2, b); if (ns * b > p2) p2 = ns * b; if ((ns + 63) / 64 * b > p2b) p2b = (ns + 63) / 64 * b;
+            for (const MsmSet<G1Aff>* m : {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}) { if (!m->nbases) continue; const size_t ns = slices_for(*m, b); if (ns * b > p1) p1 = ns * b; if ((ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * b > p1b) p1b = (ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * b; }
+            const size_t ns = slices_for(mB2, b); if (ns * b > p2) p2 = ns * b; if ((ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * b > p2b) p2b = (ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * b;
         }
         ln.d_part1a.alloc(p1); ln.d_part1b.alloc(p1b); ln.d_part2a.alloc(p2); ln.d_part2b.alloc(p2b);
         ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
@@ -399,7 +399,7 @@ class AlgorithmImpl {
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
         G1Xyzz* src = ln.d_part1a.p; G1Xyzz* alt = ln.d_part1b.p; size_t ns = nslices;
         for (;;) {
-            const size_t groups = (ns + 63) / 64;
+            const size_t groups = msm_reduce_groups(ns, B);
             G1Xyzz* dst = groups == 1 ? sum : alt;
             launch_msm_reduce_g1(src, ns, B, dst, ln.stream);
             if (groups == 1) break;
@@ -412,7 +412,7 @@ class AlgorithmImpl {
         launch_msm_g2(a, ln.stream);
         G2Xyzz* src = ln.d_part2a.p; G2Xyzz* alt = ln.d_part2b.p; size_t ns = nslices;
         for (;;) {
-            const size_t groups = (ns + 63) / 64;
+            const size_t groups = msm_reduce_groups(ns, B);
             G2Xyzz* dst = groups == 1 ? sum : alt;
             launch_msm_reduce_g2(src, ns, B, dst, ln.stream);
             if (groups == 1) break;

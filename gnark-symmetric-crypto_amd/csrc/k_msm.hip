@@ -192,6 +192,19 @@ __global__ __launch_bounds__(64) void k_msm_reduce(const fe* partial, size_t nsl
     if (threadIdx.x == 0) C::store_xyzz(out + (grp * batch + p) * (4 * F::WORDS), v);
 }
 
+// the same sum with lanes = proofs: every lane adds up to MSM_REDUCE_FANIN slice partials of ITS proof one after the other.  No lane
+// idles (the butterfly above keeps 64 lanes busy for 63 useful additions out of 384), loads are coalesced; used whenever the
+// batch is large enough to fill the chip this way (launch_msm_reduce picks).
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_reduce_seq(const fe* partial, size_t nslices, size_t batch, fe* out) {
+    using C = Curve9<F>;
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x, grp = blockIdx.y;
+    const size_t s0 = grp * MSM_REDUCE_FANIN, s1 = s0 + MSM_REDUCE_FANIN < nslices ? s0 + MSM_REDUCE_FANIN : nslices;
+    Xyzz9<F> v = C::load_xyzz(partial + (s0 * batch + p) * (4 * F::WORDS));
+    for (size_t sl = s0 + 1; sl < s1; sl++) v = C::add(v, C::load_xyzz(partial + (sl * batch + p) * (4 * F::WORDS)));
+    C::store_xyzz(out + (grp * batch + p) * (4 * F::WORDS), v);
+}
+
 // ---- proof assembly ----
 __device__ __forceinline__ void store_canon(uint8_t* dst, const fe9& mont) {      // canonical integer, 8 little-endian words
     const fe c = Fp29::pack(Fp29::from_mont(mont));
@@ -280,13 +293,19 @@ void launch_msm_g2(const MsmArgs& a, hipStream_t s) {
     if (a.nbit) hipLaunchKernelGGL((k_msm<Fp2x, true>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_msm<Fp2x, false>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
 }
-void launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_reduce<Fp29f>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
-                       reinterpret_cast<const fe*>(partial), nslices, batch, reinterpret_cast<fe*>(out));
+// returns the number of partial sums left per proof (1 = done)
+template <class F>
+static size_t launch_msm_reduce(const fe* partial, size_t nslices, size_t batch, fe* out, hipStream_t s) {
+    const size_t groups = msm_reduce_groups(nslices, batch);
+    if (msm_reduce_by_proof(nslices, batch)) hipLaunchKernelGGL(k_msm_reduce_seq<F>, dim3((unsigned)(batch / 64), (unsigned)groups), dim3(64), 0, s, partial, nslices, batch, out);
+    else hipLaunchKernelGGL(k_msm_reduce<F>, dim3((unsigned)batch, (unsigned)groups), dim3(64), 0, s, partial, nslices, batch, out);
+    return groups;
 }
-void launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_reduce<Fp2x>, dim3((unsigned)batch, (unsigned)((nslices + 63) / 64)), dim3(64), 0, s,
-                       reinterpret_cast<const fe*>(partial), nslices, batch, reinterpret_cast<fe*>(out));
+size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s) {
+    return launch_msm_reduce<Fp29f>(reinterpret_cast<const fe*>(partial), nslices, batch, reinterpret_cast<fe*>(out), s);
+}
+size_t launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s) {
+    return launch_msm_reduce<Fp2x>(reinterpret_cast<const fe*>(partial), nslices, batch, reinterpret_cast<fe*>(out), s);
 }
 void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s) {
     hipLaunchKernelGGL(k_points_to_affine_be, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, points, batch, out, flags, bit);

@@ -88,9 +88,14 @@ struct MsmArgs {
 };
 void launch_msm_g1(const MsmArgs& a, hipStream_t s);
 void launch_msm_g2(const MsmArgs& a, hipStream_t s);
-// out[proof] = sum_slices partial[slice][proof]
-void launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
-void launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
+// One reduction level: out[g][proof] = sum of the partials of group g of slices; returns the number of groups (1 = out[proof] is the
+// final sum).  Groups hold 64 slices (butterfly over lanes, small batches) or MSM_REDUCE_FANIN (lanes = proofs, large batches), so
+// `out` must have room for ceil(nslices / MSM_REDUCE_FANIN) * batch points; it must not alias `partial`.
+constexpr size_t MSM_REDUCE_FANIN = 32;
+inline bool msm_reduce_by_proof(size_t nslices, size_t batch) { return (batch / 64) * ((nslices + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN) >= 128; }   // by-proof does 8x less work; the butterfly only wins when there are too few (proof group, chunk) waves
+inline size_t msm_reduce_groups(size_t nslices, size_t batch) { const size_t f = msm_reduce_by_proof(nslices, batch) ? MSM_REDUCE_FANIN : 64; return (nslices + f - 1) / f; }
+size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
+size_t launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
 // Commitment helpers (AES-V2).  points: batch XYZZ sums -> out: batch x 64 B big-endian canonical X|Y
 // (gnark's uncompressed G1 encoding, the prefix of the commitment hash); flags[proof] |= bit if the point is infinity.
 void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s);
