@@ -76,159 +76,214 @@ struct Tile {
     }
 };
 
-// one DIF stage on the tile: pairs (e1, e1 + he); twiddle exponent = (gidx(e1) mod hg) << s.  Operands in the tile are tight or
-// signed-tight (previous sums are carried before they are written); REDUCE additionally pulls the sum path back to (-r, 2r).
-template <bool STRIDED, bool REDUCE>
-__device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, uint32_t hg, int s, int Llo, uint32_t tile_id, const int32_t* tw, const int32_t* qr) {
-    const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
-    const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
-    const uint32_t ex = (gi & (hg - 1)) << s;
-    const fe9 u = t.get(e1, q), v = t.get(e2, q);
-    const fe9 dif = F::sub(u, v), sum = F::add(u, v);
-    t.put(e1, q, REDUCE ? reduce_top(sum, qr) : F::norm(sum));
-    t.put(e2, q, ex ? F::mul(dif, load_tw(tw, ex)) : (REDUCE ? reduce_top(dif, qr) : F::norm(dif)));
+// ---- stage machinery ----------------------------------------------------------------------------------------------------
+// A workgroup has (tile elements / 4) * P threads; thread (u4, q) owns proof q of the tile.  Two radix-2 stages are done per LDS
+// round trip ("round4": four elements in registers, two stages, four butterflies), a left-over single stage is done as two
+// butterflies per thread.  Twiddle exponents are those of the plain radix-2 stages, so results are bit-identical to them.
+template <bool STRIDED> __device__ __forceinline__ uint32_t gidx(uint32_t e, int Llo, uint32_t tile_id) { return STRIDED ? ((e << Llo) + tile_id) : ((tile_id << Llo) + e); }
+// d * w, or just the carried d when the twiddle is 1 (exponent 0); REDUCE: also pull an un-multiplied value back to (-r, 2r)
+template <bool REDUCE> __device__ __forceinline__ fe9 mulw(const fe9& d, const int32_t* tw, uint32_t ex, const int32_t* qr) {
+    return ex ? F::mul(d, load_tw(tw, ex)) : (REDUCE ? reduce_top(d, qr) : F::norm(d));
 }
-// a run of DIF stages s0 .. s1-1 with one barrier per stage; the stage that completes four doublings reduces the sum path
+template <bool REDUCE> __device__ __forceinline__ fe9 carry(const fe9& x, const int32_t* qr) { return REDUCE ? reduce_top(x, qr) : F::norm(x); }
+
+// DIF.  Tile convention: entries are tight or signed-tight (sums are carried before they are written).
+// one stage s: pairs (e1, e1 + he); twiddle exponent = (gidx(e1) mod hg) << s, hg = 2^(L-1-s)
+template <bool STRIDED, bool REDUCE>
+__device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, int s, int L, int Llo, uint32_t tile_id, const NttPlan& pl) {
+    const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he, hg = 1u << (L - 1 - s);
+    const uint32_t ex = (gidx<STRIDED>(e1, Llo, tile_id) & (hg - 1)) << s;
+    const fe9 u = t.get(e1, q), v = t.get(e2, q);
+    t.put(e1, q, carry<REDUCE>(F::add(u, v), pl.qr));
+    t.put(e2, q, mulw<REDUCE>(F::sub(u, v), pl.tw_inv, ex, pl.qr));
+}
+// stages s and s+1 on elements e0 + {0, 1, 2, 3} * he2 (he2 = tile half of stage s+1): stage s pairs (e0,e2), (e1,e3), stage s+1 (e0,e1), (e2,e3)
+template <bool STRIDED, bool REDUCE>
+__device__ __forceinline__ void dif_round4(const Tile& t, uint32_t u4, uint32_t q, uint32_t he2, int s, int L, int Llo, uint32_t tile_id, const NttPlan& pl) {
+    const uint32_t e0 = 4 * u4 - 3 * (u4 & (he2 - 1)), e1 = e0 + he2, e2 = e0 + 2 * he2, e3 = e0 + 3 * he2;
+    const uint32_t hg1 = 1u << (L - 1 - s), hg2 = hg1 >> 1;
+    const uint32_t g0 = gidx<STRIDED>(e0, Llo, tile_id), g1 = gidx<STRIDED>(e1, Llo, tile_id), g2 = gidx<STRIDED>(e2, Llo, tile_id);
+    const uint32_t exA = (g0 & (hg1 - 1)) << s, exB = (g1 & (hg1 - 1)) << s, exC = (g0 & (hg2 - 1)) << (s + 1), exD = (g2 & (hg2 - 1)) << (s + 1);
+    const fe9 x0 = t.get(e0, q), x1 = t.get(e1, q), x2 = t.get(e2, q), x3 = t.get(e3, q);
+    const fe9 a0 = F::norm(F::add(x0, x2)), a1 = F::norm(F::add(x1, x3));
+    const fe9 a2 = mulw<false>(F::sub(x0, x2), pl.tw_inv, exA, pl.qr), a3 = mulw<false>(F::sub(x1, x3), pl.tw_inv, exB, pl.qr);
+    t.put(e0, q, carry<REDUCE>(F::add(a0, a1), pl.qr));
+    t.put(e1, q, mulw<REDUCE>(F::sub(a0, a1), pl.tw_inv, exC, pl.qr));
+    t.put(e2, q, carry<REDUCE>(F::add(a2, a3), pl.qr));
+    t.put(e3, q, mulw<REDUCE>(F::sub(a2, a3), pl.tw_inv, exD, pl.qr));
+}
+// DIF stages s0 .. s1-1 on a tile of E elements.  `d` = doublings of the sum path since its last range reduction (on entry: d0 <= 1);
+// a round that would leave more than four of them reduces instead (values stay below 32 r, products need < 111 r).
 template <bool STRIDED>
-__device__ __forceinline__ void dif_run(const Tile& t, uint32_t bf, uint32_t q, int s0, int s1, int done, int L, int Llo, uint32_t tile_id, const NttPlan& pl) {
-    for (int s = s0; s < s1; s++) {
-        const uint32_t hg = 1u << (L - 1 - s);
-        const uint32_t he = STRIDED ? hg >> Llo : hg;
-        if (((s - s0 + done) & 3) == 3) dif_stage<STRIDED, true>(t, bf, q, he, hg, s, Llo, tile_id, pl.tw_inv, pl.qr);
-        else dif_stage<STRIDED, false>(t, bf, q, he, hg, s, Llo, tile_id, pl.tw_inv, pl.qr);
+__device__ __forceinline__ void dif_run(const Tile& t, uint32_t u4, uint32_t q, int s0, int s1, int d0, int L, int Llo, uint32_t tile_id, const NttPlan& pl, uint32_t E) {
+    int s = s0, d = d0;
+    auto half_of = [&](int st) { const uint32_t hg = 1u << (L - 1 - st); return STRIDED ? hg >> Llo : hg; };
+    if ((s1 - s0) & 1) {
+        dif_stage<STRIDED, false>(t, u4, q, half_of(s), s, L, Llo, tile_id, pl);
+        dif_stage<STRIDED, false>(t, u4 + E / 4, q, half_of(s), s, L, Llo, tile_id, pl);
+        __syncthreads();
+        s++; d++;
+    }
+    for (; s < s1; s += 2) {
+        if (d >= 1) { dif_round4<STRIDED, true>(t, u4, q, half_of(s + 1), s, L, Llo, tile_id, pl); d = 0; }
+        else { dif_round4<STRIDED, false>(t, u4, q, half_of(s + 1), s, L, Llo, tile_id, pl); d += 2; }
         __syncthreads();
     }
 }
-// one DIT stage: half = 2^s; twiddle exponent = (gidx(e1) mod 2^s) << (L-1-s).  u is carried, v (|limb| < 2^30) goes straight into
-// the product, so both results are again single lazy sums of tight values.
+
+// DIT.  Tile convention: entries may carry one lazy addition (|limb| < 2^30); u is carried when it is read, v goes straight into
+// the product.  Values grow by at most 1.1 r per stage (a fresh product is added), so no range reduction inside a run.
+// one stage s: half = 2^s; twiddle exponent = (gidx(e1) mod 2^s) << (L-1-s)
 template <bool STRIDED>
-__device__ __forceinline__ void dit_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, int s, int L, int Llo, uint32_t tile_id, const int32_t* tw) {
+__device__ __forceinline__ void dit_stage(const Tile& t, uint32_t bf, uint32_t q, uint32_t he, int s, int L, int Llo, uint32_t tile_id, const NttPlan& pl) {
     const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
-    const uint32_t gi = STRIDED ? ((e1 << Llo) + tile_id) : ((tile_id << Llo) + e1);
-    const uint32_t ex = (gi & ((1u << s) - 1)) << (L - 1 - s);
+    const uint32_t ex = (gidx<STRIDED>(e1, Llo, tile_id) & ((1u << s) - 1)) << (L - 1 - s);
     const fe9 u = F::norm(t.get(e1, q));
-    fe9 v = t.get(e2, q);
-    v = ex ? F::mul(v, load_tw(tw, ex)) : F::norm(v);
+    const fe9 v = mulw<false>(t.get(e2, q), pl.tw_fwd, ex, pl.qr);
     t.put(e1, q, F::add(u, v)); t.put(e2, q, F::sub(u, v));
 }
+// stages s and s+1 on elements e0 + {0, 1, 2, 3} * he1 (he1 = tile half of stage s): stage s pairs (e0,e1), (e2,e3), stage s+1 (e0,e2), (e1,e3)
+template <bool STRIDED>
+__device__ __forceinline__ void dit_round4(const Tile& t, uint32_t u4, uint32_t q, uint32_t he1, int s, int L, int Llo, uint32_t tile_id, const NttPlan& pl) {
+    const uint32_t e0 = 4 * u4 - 3 * (u4 & (he1 - 1)), e1 = e0 + he1, e2 = e0 + 2 * he1, e3 = e0 + 3 * he1;
+    const uint32_t g0 = gidx<STRIDED>(e0, Llo, tile_id), g1 = gidx<STRIDED>(e1, Llo, tile_id), g2 = gidx<STRIDED>(e2, Llo, tile_id);
+    const uint32_t m1 = (1u << s) - 1, m2 = (2u << s) - 1;
+    const uint32_t exA = (g0 & m1) << (L - 1 - s), exB = (g2 & m1) << (L - 1 - s), exC = (g0 & m2) << (L - 2 - s), exD = (g1 & m2) << (L - 2 - s);
+    const fe9 n0 = F::norm(t.get(e0, q)), n2 = F::norm(t.get(e2, q));
+    const fe9 v1 = mulw<false>(t.get(e1, q), pl.tw_fwd, exA, pl.qr), v3 = mulw<false>(t.get(e3, q), pl.tw_fwd, exB, pl.qr);
+    const fe9 a0 = F::norm(F::add(n0, v1)), a1 = F::norm(F::sub(n0, v1));
+    const fe9 w2 = mulw<false>(F::add(n2, v3), pl.tw_fwd, exC, pl.qr), w3 = mulw<false>(F::sub(n2, v3), pl.tw_fwd, exD, pl.qr);
+    t.put(e0, q, F::add(a0, w2)); t.put(e2, q, F::sub(a0, w2));
+    t.put(e1, q, F::add(a1, w3)); t.put(e3, q, F::sub(a1, w3));
+}
+template <bool STRIDED>
+__device__ __forceinline__ void dit_run(const Tile& t, uint32_t u4, uint32_t q, int s0, int s1, int L, int Llo, uint32_t tile_id, const NttPlan& pl, uint32_t E) {
+    int s = s0;
+    auto half_of = [&](int st) { return STRIDED ? 1u << (st - Llo) : 1u << st; };
+    if ((s1 - s0) & 1) {
+        dit_stage<STRIDED>(t, u4, q, half_of(s), s, L, Llo, tile_id, pl);
+        dit_stage<STRIDED>(t, u4 + E / 4, q, half_of(s), s, L, Llo, tile_id, pl);
+        __syncthreads();
+        s++;
+    }
+    for (; s < s1; s += 2) { dit_round4<STRIDED>(t, u4, q, half_of(s), s, L, Llo, tile_id, pl); __syncthreads(); }
+}
 
-// K1: strided DIF head.  grid (2^Llo, batch/P, nvec); block (2^(Lhi-1) * P).  Input: the solver's a/b/c rows (canonical values of
+// K1: strided DIF head.  grid (2^Llo, batch/P, nvec); block (2^(Lhi-2) * P).  Input: the solver's a/b/c rows (canonical values of
 // the 2^256 Montgomery domain); they are used as they are — every stage is linear, and K2's scale table folds in the
 // change of domain (2^256 -> 2^261).
-__global__ void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, size_t batch) {
+__global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t G = 1u << Lhi;
     fe* vec = blockIdx.z == 0 ? v0 : blockIdx.z == 1 ? v1 : v2;
     const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
-    const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
+    const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
     Tile t{smem, G * P};
-    for (uint32_t e = bf; e < G; e += G / 2) {
+    for (uint32_t e = u4; e < G; e += G / 4) {
         const size_t idx = ((size_t)e << Llo) + g;
         t.put(e, q, idx < m ? F::load(vec + idx * batch + q0 + q) : F::zero());
     }
     __syncthreads();
-    dif_run<true>(t, bf, q, 0, Lhi, 0, L, Llo, g, pl);
-    for (uint32_t e = bf; e < G; e += G / 2) {
+    dif_run<true>(t, u4, q, 0, Lhi, 0, L, Llo, g, pl, G);
+    for (uint32_t e = u4; e < G; e += G / 4) {
         const size_t idx = ((size_t)e << Llo) + g;
         store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
 }
 
-// K2: contiguous DIF tail, coset scale, contiguous DIT head.  grid (2^Lhi, batch/P, nvec); block (2^(Llo-1) * P)
-__global__ void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batch) {
+// K2: contiguous DIF tail, coset scale, contiguous DIT head.  grid (2^Lhi, batch/P, nvec); block (2^(Llo-2) * P)
+__global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t Cn = 1u << Llo;
     fe* vec = blockIdx.z == 0 ? v0 : blockIdx.z == 1 ? v1 : v2;
     const uint32_t b = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
-    const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
+    const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
     Tile t{smem, Cn * P};
-    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
         const size_t idx = ((size_t)b << Llo) + e;
         t.put(e, q, F::load(vec + idx * batch + q0 + q));
     }
     __syncthreads();
-    dif_run<false>(t, bf, q, Lhi, L, 0, L, Llo, b, pl);
-    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+    dif_run<false>(t, u4, q, Lhi, L, 0, L, Llo, b, pl, Cn);
+    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
         const size_t idx = ((size_t)b << Llo) + e;
         t.put(e, q, F::mul(t.get(e, q), F::load(pl.scale_mid + idx)));
     }
     __syncthreads();
-    for (int s = 0; s < Llo; s++) {
-        dit_stage<false>(t, bf, q, 1u << s, s, L, Llo, b, pl.tw_fwd);
-        __syncthreads();
-    }
-    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+    dit_run<false>(t, u4, q, 0, Llo, L, Llo, b, pl, Cn);
+    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
         const size_t idx = ((size_t)b << Llo) + e;
         store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
 }
 
-// K3: strided DIT tail for a, b, c; h = (a*b - c) * den_inv; strided DIF head for h (written over a).
-__global__ void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const fe* vc, size_t batch) {
+// K3: strided DIT tail for a, b, c; h = (a*b - c) * den_inv; strided DIF head for h (written over a).  The last DIT stage and the
+// first DIF stage pair the same elements (e, e + G/2), so they stay in registers: each thread keeps two such pairs and folds
+// a, then b, then c into one running value per element (a, a*b, (a*b - c) * den_inv).
+__global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const fe* vc, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t G = 1u << Lhi;
     const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
-    const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
+    const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
     Tile t{smem, G * P};
-    fe9 r1[3], r2[3];
+    const fe9 den = F::load(pl.den_inv);
+    fe9 lo0, hi0, lo1, hi1;        // running values at elements (u4 + j*G/4) and (u4 + j*G/4 + G/2), j = 0, 1
     for (int k = 0; k < 3; k++) {
         const fe* vec = k == 0 ? va : k == 1 ? vb : vc;
-        for (uint32_t e = bf; e < G; e += G / 2) {
+        for (uint32_t e = u4; e < G; e += G / 4) {
             const size_t idx = ((size_t)e << Llo) + g;
             t.put(e, q, F::load(vec + idx * batch + q0 + q));
         }
         __syncthreads();
-        for (int s = Llo; s < L - 1; s++) {
-            dit_stage<true>(t, bf, q, 1u << (s - Llo), s, L, Llo, g, pl.tw_fwd);
-            __syncthreads();
-        }
-        {   // last DIT stage (s = L-1): pairs (bf, bf + G/2), results stay in registers
-            const uint32_t e1 = bf, e2 = bf + G / 2;
+        dit_run<true>(t, u4, q, Llo, L - 1, L, Llo, g, pl, G);
+        auto last_dit = [&](uint32_t e1, fe9& lo, fe9& hi) {   // last DIT stage (s = L-1): pair (e1, e1 + G/2)
+            const uint32_t e2 = e1 + G / 2;
             const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
             const fe9 u = F::norm(t.get(e1, q));
-            fe9 v = t.get(e2, q);
-            v = ex ? F::mul(v, load_tw(pl.tw_fwd, ex)) : F::norm(v);
-            const fe9 a1 = F::norm(F::add(u, v)), a2 = F::norm(F::sub(u, v));      // tight; |value| <= 2^256/r + 8 * 1.1 < 15 r
-            if (k == 0) { r1[0] = a1; r2[0] = a2; } else if (k == 1) { r1[1] = a1; r2[1] = a2; } else { r1[2] = a1; r2[2] = a2; }
-        }
+            const fe9 v = mulw<false>(t.get(e2, q), pl.tw_fwd, ex, pl.qr);
+            const fe9 x1 = F::norm(F::add(u, v)), x2 = F::norm(F::sub(u, v));      // tight; |value| <= 2^256/r + 8 * 1.1 < 15 r
+            if (k == 0) { lo = x1; hi = x2; }
+            else if (k == 1) { lo = F::mul(lo, x1); hi = F::mul(hi, x2); }                                   // a*b in (-1.4r, 2.4r)
+            else { lo = F::mul(F::sub(lo, x1), den); hi = F::mul(F::sub(hi, x2), den); }                     // |a*b - c| < 18 r, signed-tight
+        };
+        last_dit(u4, lo0, hi0);
+        last_dit(u4 + G / 4, lo1, hi1);
         __syncthreads();
     }
-    const fe9 den = F::load(pl.den_inv);
-    const fe9 h1 = F::mul(F::sub(F::mul(r1[0], r1[1]), r1[2]), den);     // a*b in (-1.4r, 2.4r), minus c: |.| < 18 r, signed-tight: fine as a product operand
-    const fe9 h2 = F::mul(F::sub(F::mul(r2[0], r2[1]), r2[2]), den);
-    {   // first DIF stage (s = 0): same pairs; twiddle exponent = gidx(e1) mod n/2
-        const uint32_t e1 = bf, e2 = bf + G / 2;
+    auto first_dif = [&](uint32_t e1, const fe9& lo, const fe9& hi) {       // first DIF stage (s = 0) on h: same pairs; twiddle exponent = gidx(e1) mod n/2
+        const uint32_t e2 = e1 + G / 2;
         const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
-        const fe9 dif = F::sub(h1, h2);
-        t.put(e1, q, F::norm(F::add(h1, h2)));
-        t.put(e2, q, ex ? F::mul(dif, load_tw(pl.tw_inv, ex)) : F::norm(dif));
-    }
+        t.put(e1, q, F::norm(F::add(lo, hi)));
+        t.put(e2, q, mulw<false>(F::sub(lo, hi), pl.tw_inv, ex, pl.qr));
+    };
+    first_dif(u4, lo0, hi0);
+    first_dif(u4 + G / 4, lo1, hi1);
     __syncthreads();
-    dif_run<true>(t, bf, q, 1, Lhi, 1, L, Llo, g, pl);
-    for (uint32_t e = bf; e < G; e += G / 2) {
+    dif_run<true>(t, u4, q, 1, Lhi, 1, L, Llo, g, pl, G);
+    for (uint32_t e = u4; e < G; e += G / 4) {
         const size_t idx = ((size_t)e << Llo) + g;
         store_lazy(va + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
 }
 
 // K4: contiguous DIF tail on h, then scale by n^-1 g^-j and leave Montgomery form (canonical output in [0, r)).
-__global__ void k_ntt_final_contig(NttPlan pl, fe* vh, size_t batch) {
+__global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t Cn = 1u << Llo;
     const uint32_t b = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
-    const uint32_t q = threadIdx.x % P, bf = threadIdx.x / P;
+    const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
     Tile t{smem, Cn * P};
-    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
         const size_t idx = ((size_t)b << Llo) + e;
         t.put(e, q, F::load(vh + idx * batch + q0 + q));
     }
     __syncthreads();
-    dif_run<false>(t, bf, q, Lhi, L, 0, L, Llo, b, pl);
-    for (uint32_t e = bf; e < Cn; e += Cn / 2) {
+    dif_run<false>(t, u4, q, Lhi, L, 0, L, Llo, b, pl, Cn);
+    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
         const size_t idx = ((size_t)b << Llo) + e;
         F::store(vh + idx * batch + q0 + q, F::mul(t.get(e, q), F::load(pl.scale_out + idx)));
     }
@@ -245,10 +300,10 @@ void launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t ba
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_dif_strided), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pointwise_strided), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
     }
-    hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, 3), dim3(G / 2 * P), lds_s, s, p, a, b, c, m, batch);
-    hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 3), dim3(Cn / 2 * P), lds_c, s, p, a, b, c, batch);
-    hipLaunchKernelGGL(k_ntt_pointwise_strided, dim3(Cn, pb, 1), dim3(G / 2 * P), lds_s, s, p, a, b, c, batch);
-    hipLaunchKernelGGL(k_ntt_final_contig, dim3(G, pb, 1), dim3(Cn / 2 * P), lds_c, s, p, a, batch);
+    hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch);
+    hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 3), dim3(Cn / 4 * P), lds_c, s, p, a, b, c, batch);
+    hipLaunchKernelGGL(k_ntt_pointwise_strided, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, c, batch);
+    hipLaunchKernelGGL(k_ntt_final_contig, dim3(G, pb, 1), dim3(Cn / 4 * P), lds_c, s, p, a, batch);
 }
 
 }  // namespace gsc
