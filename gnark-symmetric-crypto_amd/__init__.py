@@ -118,6 +118,16 @@ def prove_raw(cipher: int, records: bytes, n: int):
     return ok, proofs.raw, list(lens), cts.raw
 
 
+def raw_buffers(n: int):
+    """Reusable output buffers for prove_raw_into: (proofs[n][196], lens[n] u32, ciphertexts[n][64])."""
+    return C.create_string_buffer(196 * n), (C.c_uint32 * n)(), C.create_string_buffer(64 * n)
+
+
+def prove_raw_into(cipher: int, records: bytes, n: int, proofs, lens, cts) -> int:
+    """prove_raw without per-call allocations and copies: fills caller-owned buffers (raw_buffers), returns the number of proofs produced."""
+    return lib().gsc_prove_raw(cipher, records, n, proofs, lens, cts)
+
+
 def set_deterministic_randomness(r=None, s=None, mask=0):
     """TEST HOOK: fix (r, s, mask) as integers; None restores the CSPRNG."""
     if r is None:

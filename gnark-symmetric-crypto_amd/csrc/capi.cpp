@@ -14,6 +14,7 @@
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -80,10 +81,26 @@ DebugVectors g_debug;
 const uint8_t kFrModBE[32] = {0x30, 0x64, 0x4e, 0x72, 0xe1, 0x31, 0xa0, 0x29, 0xb8, 0x50, 0x45, 0xb6, 0x81, 0x81, 0x58, 0x5d,
                               0x28, 0x33, 0xe8, 0x48, 0x79, 0xb9, 0x70, 0x91, 0x43, 0xe1, 0xf5, 0x93, 0xf0, 0x00, 0x00, 0x01};
 
+// OS CSPRNG bytes, fetched 16 KiB at a time per thread: a batch of 8192 proofs draws ~25 000 scalars, and one getrandom() system
+// call per scalar was a measurable part of the step (the GPU idles meanwhile).  The buffer is wiped as it is consumed.
+void csprng_bytes(uint8_t* out, size_t n) {
+    thread_local uint8_t pool[16384]; thread_local size_t have = 0;
+    while (n) {
+        if (!have) {
+            size_t got = 0;
+            while (got < sizeof pool) { ssize_t k = getrandom(pool + got, sizeof pool - got, 0); if (k > 0) got += (size_t)k; }
+            have = sizeof pool;
+        }
+        const size_t take = n < have ? n : have;
+        uint8_t* src = pool + (sizeof pool - have);
+        memcpy(out, src, take);
+        volatile uint8_t* wipe = src; for (size_t i = 0; i < take; i++) wipe[i] = 0;
+        out += take; n -= take; have -= take;
+    }
+}
 void random_fr_le(uint8_t out[32]) {   // uniform in [0, r) by rejection (fr.SetRandom in the reference)
     for (;;) {
-        uint8_t be[32]; size_t got = 0;
-        while (got < 32) { ssize_t k = getrandom(be + got, 32 - got, 0); if (k > 0) got += (size_t)k; }
+        uint8_t be[32]; csprng_bytes(be, 32);
         be[0] &= 0x3F;
         if (memcmp(be, kFrModBE, 32) < 0) { for (int i = 0; i < 32; i++) out[i] = be[31 - i]; return; }
     }
@@ -290,6 +307,8 @@ long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t
     Algorithm* a = lookup(cipher);
     if (!a) return -1;
     try {
+        const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<ProofRequest> reqs(n); std::vector<ProofResult> res(n);
         for (size_t i = 0; i < n; i++) {
             const uint8_t* rec = inputs + 112 * i; ProofRequest& q = reqs[i]; memset(&q, 0, sizeof q);
@@ -300,7 +319,10 @@ long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t
             else aes_ctr_xor_stream(q.key, q.keylen, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
             fill_randomness(q);
         }
+        const auto t1 = std::chrono::steady_clock::now();
         a->prove_batch(reqs.data(), n, res.data());
+        const auto t2 = std::chrono::steady_clock::now();
+        if (trace) fprintf(stderr, "gsc_prove_raw: prepare %.2f ms, prove_batch %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
         long long good = 0;
         for (size_t i = 0; i < n; i++) {
             if (ciphertexts) memcpy(ciphertexts + 64 * i, reqs[i].ciphertext, 64);

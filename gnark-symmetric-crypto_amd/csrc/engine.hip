@@ -4,6 +4,7 @@
 #include "formats.hpp"
 #include "kernels.hpp"
 #include "host_ciphers.hpp"
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -428,6 +429,8 @@ class AlgorithmImpl {
 
     void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg) {
         const size_t B = (n + 63) / 64 * 64;
+        const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
+        const auto tc0 = std::chrono::steady_clock::now();
         std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs, n, B, h_in, h_rs);
         ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
         ln.d_rs.upload(h_rs.data(), h_rs.size(), ln.stream);
@@ -497,11 +500,18 @@ class AlgorithmImpl {
         HIP_CHECK(hipMemcpyAsync(h_flags.data(), ln.d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, ln.stream));
         HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
         if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data() + 64 * B, ln.d_cpts.p + 64 * B, 64 * B, hipMemcpyDeviceToHost, ln.stream));
+        const auto tc1 = std::chrono::steady_clock::now();
         HIP_CHECK(hipStreamSynchronize(ln.stream));
+        const auto tc2 = std::chrono::steady_clock::now();
         for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
         (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
         for (size_t i = 0; i < n; i++)
             serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts.data() + 64 * i : nullptr, has_commitment ? h_cpts.data() + 64 * B + 64 * i : nullptr, results[i]);
+        if (trace) {
+            const auto tc3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "prove_chunk(%zu): enqueue %.2f ms, wait %.2f ms, serialise %.2f ms\n", n, ms(tc0, tc1), ms(tc1, tc2), ms(tc2, tc3));
+        }
     }
 
     // gnark proof.WriteTo: Ar | Bs | Krs compressed, u32be nbCommitments, commitments, CommitmentPok
