@@ -56,6 +56,8 @@ struct MsmSet {                     // one fixed-base MSM: tables + scalar row m
     DevBuf<AffT> table; DevBuf<uint32_t> rows; size_t nbases = 0; int c = 0, nwin = 0; size_t nslices = 0;
     // bases [0, nbit) are grouped in eights with subset-sum tables (kernels.hpp MsmArgs)
     size_t nbit = 0; DevBuf<AffT> sub; DevBuf<uint8_t> group_ok;
+    // bases [0, nwide) additionally have a table with wider digits
+    size_t nwide = 0; DevBuf<AffT> table2; int c2 = 0, nwin2 = 0;
 };
 
 }  // namespace
@@ -67,8 +69,10 @@ EngineConfig config_from_env() {
     c.lanes = env_int("GSC_LANES", 1);
     c.min_split = (size_t)env_int("GSC_MIN_SPLIT", 256);
     c.bit_groups = env_int("GSC_BIT_GROUPS", 1);
+    c.wide_table_gb = env_int("GSC_WIDE_TABLE_GB", 16);
     c.window_z = env_int("GSC_WINDOW_Z", 0);
     c.window_w = env_int("GSC_WINDOW_W", 0);
+    c.window_wide = env_int("GSC_WINDOW_WIDE", 0);
     c.z_table_gb = env_int("GSC_Z_TABLE_GB", 48);
     c.w_table_gb = env_int("GSC_W_TABLE_GB", 24);
     if (c.max_batch < 64) c.max_batch = 64;
@@ -85,7 +89,8 @@ class AlgorithmImpl {
     std::mutex mu;
     hipStream_t stream = nullptr;   // init-time work; proving runs on the lanes' streams
     size_t table_bytes = 0;
-    std::vector<uint8_t> row_is_bit;   // per scalar row (wire): predicted to be 0 or 1 in every proof (calibrate_bits)
+    std::vector<uint8_t> row_class;    // per scalar row (wire), predicted by calibrate(): 0 = always 0 or 1, else the largest bit length seen (255 = unknown)
+    static constexpr int WIDE_BITS = 64;   // wires seen above this are given wide-digit tables
 
     // program
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
@@ -120,7 +125,7 @@ class AlgorithmImpl {
         R1csFile cs = parse_r1cs(r1cs, r1cs_len);
         PkFile key = parse_pk(pk, pk_len);
         init_program(cs);
-        calibrate_bits();
+        calibrate();
         init_key(cs, key);
         // lanes: GSC_LANES (default 1) as long as each keeps at least 64 proofs
         size_t nl = (size_t)cfg.lanes; if (nl < 1) nl = 1;
@@ -177,10 +182,11 @@ class AlgorithmImpl {
     // pseudo-random statements once and call a wire a bit when it is 0 or 1 in all of them.  This is only a PREDICTION used to
     // lay out the wire MSMs (bit wires first, in groups of eight with subset-sum tables); k_msm re-checks every group for
     // every wave of proofs and falls back to the digit tables, so a wrong prediction costs time, never correctness.
-    void calibrate_bits() {
-        row_is_bit.assign(n_wires + 4, 0);
+    void calibrate() {
+        row_class.assign(n_wires + 4, 255);
+        row_class[n_wires] = row_class[n_wires + 1] = row_class[n_wires + 2] = 254;     // r, s, -rs: uniform scalars
         if (cfg.bit_groups <= 0) return;
-        if (cfg.bit_groups >= 2) { std::fill(row_is_bit.begin(), row_is_bit.begin() + n_wires, 1); return; }
+        if (cfg.bit_groups >= 2) { std::fill(row_class.begin(), row_class.begin() + n_wires, 0); return; }
         const size_t B = 64;
         std::vector<ProofRequest> reqs(B);
         uint64_t x = 0x9E3779B97F4A7C15ull;
@@ -212,21 +218,10 @@ class AlgorithmImpl {
             sa.first_level = l; sa.n_long = level_long[l];
             if (level_kind[l]) launch_solver_count_level(sa, level_width[l], stream); else launch_solver_level(sa, level_width[l], stream);
         }
-        std::vector<uint32_t> h_W(n_wires * B * 8), h_status(B);
-        HIP_CHECK(hipMemcpyAsync(h_W.data(), d_W.p, n_wires * B * 32, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, B * 4, hipMemcpyDeviceToHost, stream));
+        DevBuf<uint8_t> d_cls(n_wires);
+        launch_classify_wires(d_W.p, n_wires, B, d_status.p, d_cls.p, stream);
+        HIP_CHECK(hipMemcpyAsync(row_class.data(), d_cls.p, n_wires, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        static const uint32_t one[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};   // 2^256 mod r
-        for (size_t w = 0; w < n_wires; w++) {
-            bool bit = true;
-            for (size_t p = 0; p < B && bit; p++) {
-                if (h_status[p] != 0xFFFFFFFFu) continue;          // a statement the solver rejected says nothing
-                const uint32_t* v = h_W.data() + (w * B + p) * 8;
-                uint32_t z = 0, o = 0; for (int i = 0; i < 8; i++) { z |= v[i]; o |= v[i] ^ one[i]; }
-                bit = z == 0 || o == 0;
-            }
-            row_is_bit[w] = bit;
-        }
     }
 
     // decompress `raw` (count points of `sz` bytes) into out[offset...]; returns per-point status
@@ -255,15 +250,26 @@ class AlgorithmImpl {
     void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build, size_t bases_per_slice = 16, bool wire_scalars = true) {
         const size_t n = raw.size() / point_bytes;
         if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
-        {   // bases whose scalars are predicted to be bits go first (stable order otherwise); the point at infinity never does
-            std::vector<size_t> order; order.reserve(n);
-            auto is_bit = [&](size_t i) { return wire_scalars && rows[i] < row_is_bit.size() && row_is_bit[rows[i]] && (raw[i * point_bytes] & 0xC0) != 0x40; };
-            for (size_t i = 0; i < n; i++) if (is_bit(i)) order.push_back(i);
-            set.nbit = order.size() / 8 * 8;
-            if (set.nbit) {
-                std::vector<uint8_t> taken(n, 0);
-                order.resize(set.nbit); for (size_t i : order) taken[i] = 1;
-                for (size_t i = 0; i < n; i++) if (!taken[i]) order.push_back(i);
+        {   // order: [predicted full-width][predicted bits, in eights][the rest] (stable inside each part); the point at infinity is "rest"
+            auto cls = [&](size_t i) -> int { return !wire_scalars || rows[i] >= row_class.size() || (raw[i * point_bytes] & 0xC0) == 0x40 ? 255 : row_class[rows[i]]; };
+            const bool layout = wire_scalars && cfg.bit_groups > 0;
+            std::vector<size_t> wide, bits, rest;
+            for (size_t i = 0; i < n; i++) {
+                const int c0 = cls(i);
+                if (layout && c0 == 0) bits.push_back(i);
+                else if (layout && c0 != 255 && c0 > WIDE_BITS) wide.push_back(i);
+                else rest.push_back(i);
+            }
+            while (wide.size() % 8 && !wide.empty()) {         // the bit groups behind must start at a multiple of 8: top up with other bases
+                if (!rest.empty()) { wide.push_back(rest.back()); rest.pop_back(); }
+                else if (!bits.empty()) { wide.push_back(bits.back()); bits.pop_back(); }
+                else break;
+            }
+            if (wide.size() % 8) { rest.insert(rest.begin(), wide.begin(), wide.end()); wide.clear(); }
+            while (bits.size() % 8) { rest.insert(rest.begin(), bits.back()); bits.pop_back(); }
+            set.nwide = wide.size(); set.nbit = bits.size();
+            if (set.nwide || set.nbit) {
+                std::vector<size_t> order(wide); order.insert(order.end(), bits.begin(), bits.end()); order.insert(order.end(), rest.begin(), rest.end());
                 std::vector<uint8_t> raw2(raw.size()); std::vector<uint32_t> rows2(n);
                 for (size_t j = 0; j < n; j++) { memcpy(raw2.data() + j * point_bytes, raw.data() + order[j] * point_bytes, point_bytes); rows2[j] = rows[order[j]]; }
                 raw.swap(raw2); rows.swap(rows2);
@@ -288,7 +294,13 @@ class AlgorithmImpl {
             const size_t ng = set.nbit / 8;
             set.sub.alloc(ng * 255); set.group_ok.alloc(ng);
             table_bytes += set.sub.bytes();
-            build_subset(bases.p, ng, set.sub.p, set.group_ok.p);
+            build_subset(bases.p + set.nwide, ng, set.sub.p, set.group_ok.p);
+        }
+        if (set.nwide) {
+            set.c2 = cfg.window_wide > c ? cfg.window_wide : c; set.nwin2 = (254 + set.c2 - 1) / set.c2;
+            set.table2.alloc(set.nwide * set.nwin2 * ((size_t)1 << (set.c2 - 1)));
+            table_bytes += set.table2.bytes();
+            build(bases.p, set.nwide, set.c2, set.nwin2, set.table2.p);
         }
         HIP_CHECK(hipStreamSynchronize(stream));
     }
@@ -333,6 +345,11 @@ class AlgorithmImpl {
         if (!cfg.window_w) {
             const size_t g1n = rowsA.size() + rowsB.size() + rowsK.size() + 2 * cs.commit_private.size(), g2n = rowsB2.size();
             cfg.window_w = 3; for (int c = 8; c >= 3; c--) if (table_bytes_for(g1n, c, 64) + table_bytes_for(g2n, c, 128) <= cfg.w_table_gb * 1e9) { cfg.window_w = c; break; }
+        }
+        if (!cfg.window_wide) {      // wide-digit tier: the widest digits whose tables for the predicted full-width wires fit the budget
+            auto nwide = [&](const std::vector<uint32_t>& rows) { size_t k = 0; for (uint32_t r : rows) if (r < row_class.size() && row_class[r] != 255 && row_class[r] > WIDE_BITS) k++; return k + 8; };
+            const size_t g1w = nwide(rowsA) + nwide(rowsB) + nwide(rowsK) + 2 * nwide(cs.commit_private), g2w = nwide(rowsB2);
+            cfg.window_wide = cfg.window_w; for (int c = 13; c > cfg.window_w; c--) if (table_bytes_for(g1w, c, 64) + table_bytes_for(g2w, c, 128) <= cfg.wide_table_gb * 1e9) { cfg.window_wide = c; break; }
         }
         auto dec1 = [this](const std::vector<uint8_t>& raw, G1Aff* out) { return decompress_g1(raw, out); };
         auto dec2 = [this](const std::vector<uint8_t>& raw, G2Aff* out) { return decompress_g2(raw, out); };
@@ -394,7 +411,7 @@ class AlgorithmImpl {
     }
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
         const size_t nslices = slices_for(set, B);
-        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part1a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p};
+        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part1a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p, mont ? set.nwide : 0, set.table2.p, set.c2, set.nwin2};
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
         launch_msm_g1(a, ln.stream);
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
@@ -409,7 +426,7 @@ class AlgorithmImpl {
     }
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
         const size_t nslices = slices_for(set, B);
-        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part2a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p};
+        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part2a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p, mont ? set.nwide : 0, set.table2.p, set.c2, set.nwin2};
         launch_msm_g2(a, ln.stream);
         G2Xyzz* src = ln.d_part2a.p; G2Xyzz* alt = ln.d_part2b.p; size_t ns = nslices;
         for (;;) {
@@ -566,8 +583,8 @@ void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) 
 float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impl_->lanes[0]->last_batch; if (nbases) *nbases = impl_->mZ.nbases; return impl_->lanes[0]->msm_z_kernel_ms; }
 std::string Algorithm::describe() const {
     char buf[512];
-    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu",
-             impl_->n_wires, impl_->n_constraints, impl_->L, impl_->cap, impl_->lanes.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
+    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu window_z=%d window_w=%d window_wide=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu",
+             impl_->n_wires, impl_->n_constraints, impl_->L, impl_->cap, impl_->lanes.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->cfg.window_wide, impl_->table_bytes / 1073741824.0,
              impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases);
     return buf;
 }

@@ -33,8 +33,10 @@ struct EngineConfig {
     size_t min_split = 256;      // a call with at least 2*min_split proofs is spread over the lanes (GSC_MIN_SPLIT)
     int window_z = 0;            // digit width of the Z (quotient) tables; 0 = largest that fits z_table_gb (ChaCha: 12 -> 94 GB, 13 -> 172 GB; bench.py uses 13)
     int window_w = 0;            // digit width of the A / B1 / B2 / K / commitment tables; 0 = largest <= 8 that fits w_table_gb
+    int window_wide = 0;         // digit width of the second table tier (wires predicted full-width); 0 = largest <= 13 that fits wide_table_gb
     int z_table_gb = 48, w_table_gb = 24;   // per-algorithm HBM budgets used when the widths are not given
-    int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no subset tables; 1 for the wires a calibration witness predicts to be bits; 2 for every wire (test: exercises the fallback)
+    int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no prediction-based layout; 1 bit groups / wide-digit tier from a calibration witness; 2 every wire predicted a bit (test: exercises the fallback)
+    int wide_table_gb = 16;      // GSC_WIDE_TABLE_GB: budget of the wide-digit tables for wires predicted to carry full-width scalars
 };
 EngineConfig config_from_env();
 

@@ -83,16 +83,15 @@ __device__ __forceinline__ Aff9<Fp2x> unpack_aff(const RawAff<Fp2x>& r, bool neg
 template <class F, bool EXACT, bool BITS>
 __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0, size_t k1, size_t p) {
     using C = Curve9<F>;
-    const uint32_t c = a.c, nwin = a.nwin, D = 1u << (c - 1);
-    const fe* table = reinterpret_cast<const fe*>(a.table);
     const fe* sub = reinterpret_cast<const fe*>(a.sub);
+    const size_t bit0 = BITS ? a.nwide : 0, bit1 = BITS ? a.nwide + a.nbit : 0;
     Xyzz9<F> acc = C::infinity();
     RawAff<F> pend; bool have = false, pend_neg = false;
     auto scalar_of = [&](size_t k) { const size_t row = a.rows ? uni(a.rows[k]) : k; return load_fe(a.scalars + row * a.batch + p); };
     size_t k = k0, single_until = 0;        // bases below single_until are walked one by one even inside the bit-group region
     fe s_next = fe{}; bool have_next = false;
     while (k < k1) {
-        if (BITS && k < a.nbit && k >= single_until) {      // wave-uniform: k is a multiple of 8 here
+        if (BITS && k >= bit0 && k < bit1 && k >= single_until) {      // wave-uniform: k is a multiple of 8 here
             uint32_t mask = 0; bool ok = true;
 #pragma unroll 1
             for (int h = 0; h < 8; h += 4) {        // four scalars in flight at a time: eight would cost a wave of occupancy
@@ -108,9 +107,10 @@ __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0
                     mask |= (o == 0 ? 1u : 0u) << (h + b);
                 }
             }
-            if (__all(ok) && uni(a.group_ok[k >> 3])) {
+            const size_t grp = (k - bit0) >> 3;
+            if (__all(ok) && uni(a.group_ok[grp])) {
                 if (mask) {
-                    const RawAff<F> nxt = load_raw<F>(sub + ((k >> 3) * 255 + (mask - 1)) * (2 * F::WORDS));
+                    const RawAff<F> nxt = load_raw<F>(sub + (grp * 255 + (mask - 1)) * (2 * F::WORDS));
                     if (have) acc = C::template madd<EXACT>(acc, unpack_aff(pend, pend_neg));
                     pend = nxt; pend_neg = false; have = true;
                 }
@@ -120,10 +120,14 @@ __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0
             single_until = k + 8; have_next = false;
         }
         fe s = have_next ? s_next : scalar_of(k);
-        have_next = k + 1 < k1 && (!BITS || k + 1 >= a.nbit || k + 1 < single_until);
+        have_next = k + 1 < k1 && (!BITS || k + 1 < bit0 || k + 1 >= bit1 || k + 1 < single_until);
         if (have_next) s_next = scalar_of(k + 1);
         if (a.scalars_mont) s = Fr::from_mont(s);
         const bool neg = sign_normalise(s);
+        // digit table of this base (wave-uniform): the wide-digit table for the bases predicted to carry full-width scalars
+        const bool wide = BITS && k < a.nwide;
+        const uint32_t c = wide ? (uint32_t)a.c2 : (uint32_t)a.c, nwin = wide ? (uint32_t)a.nwin2 : (uint32_t)a.nwin, D = 1u << (c - 1);
+        const fe* table = reinterpret_cast<const fe*>(wide ? a.table2 : a.table);
         // number of windows this lane needs: highest set bit / c + 1 (+1 for a possible carry)
         int top = -1;
 #pragma unroll
@@ -203,6 +207,30 @@ __global__ __launch_bounds__(64) void k_msm_reduce_seq(const fe* partial, size_t
     Xyzz9<F> v = C::load_xyzz(partial + (s0 * batch + p) * (4 * F::WORDS));
     for (size_t sl = s0 + 1; sl < s1; sl++) v = C::add(v, C::load_xyzz(partial + (sl * batch + p) * (4 * F::WORDS)));
     C::store_xyzz(out + (grp * batch + p) * (4 * F::WORDS), v);
+}
+
+// ---- calibration: what do the wires of this circuit look like? (engine.hip calibrate) ----
+__global__ __launch_bounds__(64) void k_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint32_t* status, uint8_t* cls) {
+    const size_t w = blockIdx.x;                 // one wave per wire, lanes = proofs (strided over the batch)
+    if (w >= n_wires) return;
+    int worst = 0;
+    for (size_t p = threadIdx.x; p < batch; p += 64) {
+        if (status[p] != 0xFFFFFFFFu) continue;  // a statement the solver rejected says nothing
+        fe s = load_fe(W + w * batch + p);
+        uint32_t z = 0, o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { z |= s.l[i]; o |= s.l[i] ^ FrParams::one(i); }
+        if (z == 0 || o == 0) continue;          // 0 or 1
+        s = Fr::from_mont(s);
+        (void)sign_normalise(s);
+        int top = 0;
+#pragma unroll
+        for (int i = 7; i >= 0; i--) if (!top && s.l[i]) top = 32 * i + 32 - __clz(s.l[i]);
+        if (top < 2) top = 2;                    // a value that is not 0/1 but has magnitude 1 is -1
+        worst = top > worst ? top : worst;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(worst, m); worst = o > worst ? o : worst; }
+    if (threadIdx.x == 0) cls[w] = (uint8_t)worst;
 }
 
 // ---- proof assembly ----
@@ -306,6 +334,9 @@ size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch,
 }
 size_t launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s) {
     return launch_msm_reduce<Fp2x>(reinterpret_cast<const fe*>(partial), nslices, batch, reinterpret_cast<fe*>(out), s);
+}
+void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint32_t* status, uint8_t* cls, hipStream_t s) {
+    if (n_wires) hipLaunchKernelGGL(k_classify_wires, dim3((unsigned)n_wires), dim3(64), 0, s, W, n_wires, batch, status, cls);
 }
 void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s) {
     hipLaunchKernelGGL(k_points_to_affine_be, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, points, batch, out, flags, bit);

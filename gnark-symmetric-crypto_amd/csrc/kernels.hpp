@@ -66,6 +66,10 @@ void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint
 void launch_build_subset_g1(const G1Aff* bases, size_t ngroups, G1Aff* table, G1Xyzz* scratch, uint8_t* ok, hipStream_t s);
 void launch_build_subset_g2(const G2Aff* bases, size_t ngroups, G2Aff* table, G2Xyzz* scratch, uint8_t* ok, hipStream_t s);
 
+// Calibration: cls[w] = 0 if wire w is 0 or 1 in every accepted proof of the batch (status == 0xFFFFFFFF), otherwise the largest bit
+// length of its sign-normalised value (1..254).  W: [n_wires][batch] Montgomery.
+void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint32_t* status, uint8_t* cls, hipStream_t s);
+
 // ---- quotient polynomial (k_ntt.hip) ----
 struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* den_inv; const int32_t* qr; };   // tw_*, qr: 12 int32 per entry (limbs)
 constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_QMAX .. NTT_QMAX (range reduction by the top limb)
@@ -82,9 +86,13 @@ struct MsmArgs {
     int scalars_mont;              // 1: Montgomery form, 0: canonical
     size_t batch; size_t nslices;  // slices of ceil(nbases/nslices) consecutive bases, rounded up to a multiple of 8
     void* partial;                 // G1Xyzz / G2Xyzz [nslices][batch]
-    // bit groups: bases [0, nbit) (nbit a multiple of 8) carry scalars that are 0 or 1 in nearly every proof; group g = bases
-    // 8g..8g+7 has a subset-sum table sub[g][m-1] = sum_{b in m} base_{8g+b} (255 affine entries) and group_ok[g] != 0
+    // Layout of a wire set, predicted at InitAlgorithm (never trusted for correctness):
+    //   bases [0, nwide)            full-width scalars: a second digit table with wider digits (table2, c2, nwin2; base index k)
+    //   bases [nwide, nwide + nbit) scalars that are 0 or 1 in nearly every proof (nwide, nbit multiples of 8): group g = bases
+    //                               nwide+8g .. +7 has a subset-sum table sub[g][m-1] = sum_{b in m} base (255 affine entries), group_ok[g] != 0
+    //   the rest                    everything else, through `table`
     size_t nbit; const void* sub; const uint8_t* group_ok;
+    size_t nwide; const void* table2; int c2, nwin2;
 };
 void launch_msm_g1(const MsmArgs& a, hipStream_t s);
 void launch_msm_g2(const MsmArgs& a, hipStream_t s);
