@@ -57,10 +57,10 @@ def shard_bounds(total, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_proofs(dist, local: "torch.Tensor", rank, world):
+def gather_proofs(dist, local: "torch.Tensor", rank, world, use_dist=None):
     """The path's only exchange: every rank's finished proofs (164 B each) to rank 0."""
     import torch
-    if world == 1:
+    if not (world > 1 if use_dist is None else use_dist):
         return [local]
     out = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
     dist.gather(local, out, dst=0)
@@ -101,9 +101,15 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("GSC_BENCH_BATCH", "8192")), help="proofs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (rehearsal of the multi-GPU code path on a one-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE JSON line (rank 0).  Native libraries print there too (libprove reports errors on stdout like the
+    # reference's fmt.Println, RCCL prints a banner), so file descriptor 1 is pointed at stderr for the whole run and the line is
+    # written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1); os.dup2(2, 1)
     os.environ["GSC_DEVICE"] = str(local_rank)
     os.environ.setdefault("GSC_MAX_BATCH", str(args.batch))
     import torch
@@ -111,8 +117,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the prover has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import gsc_loader
@@ -121,18 +128,12 @@ def main():
     # hold them (InitAlgorithm reports the failure and leaves the algorithm uninitialised, so it can simply be retried)
     pk, r1cs = golden("pk.chacha20"), golden("r1cs.chacha20")
     wanted = [os.environ["GSC_WINDOW_Z"]] if os.environ.get("GSC_WINDOW_Z") else ["13", "12", "11", "0"]
-    # the library reports errors on stdout like the reference (fmt.Println); keep this process' stdout for the one JSON line
-    sys.stdout.flush()
-    saved = os.dup(1); os.dup2(2, 1)
-    try:
-        for wz in wanted:
-            os.environ["GSC_WINDOW_Z"] = wz
-            if g.init_algorithm(g.CHACHA20, pk, r1cs):
-                break
-        else:
-            raise SystemExit("InitAlgorithm failed")
-    finally:
-        os.dup2(saved, 1); os.close(saved)
+    for wz in wanted:
+        os.environ["GSC_WINDOW_Z"] = wz
+        if g.init_algorithm(g.CHACHA20, pk, r1cs):
+            break
+    else:
+        raise SystemExit("InitAlgorithm failed")
 
     B = args.batch
     dev = torch.device("cuda", local_rank)
@@ -147,10 +148,10 @@ def main():
         if ok != B:
             raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, ok, B))
         local = torch.frombuffer(proofs_buf, dtype=torch.uint8).to(dev)
-        return gather_proofs(dist, local, rank, world), None
+        return gather_proofs(dist, local, rank, world, use_dist), None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +166,7 @@ def main():
         kernel_ms.append(g.last_msm_z_kernel(g.CHACHA20))
     barrier()
     elapsed = time.time() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -199,8 +200,9 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(cores)
             except Exception as e:      # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 
