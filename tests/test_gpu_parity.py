@@ -230,3 +230,32 @@ def test_engine_options_do_not_change_the_proofs_aes(aes_keys):
     base = _digest({}, 1, pk_path)
     for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}):
         assert _digest(extra, 1, pk_path) == base, extra
+
+
+def test_bench_size_batch_every_proof_verifies(gsc_chacha):
+    # Full BASELINE size and beyond (4096 statements in one call, CSPRNG randomness): EVERY proof is checked with the drop-in verifier
+    # under the reference's vk.chacha20 (three pairings each, on the host cores), plus ciphertext = ChaCha20(key, nonce, counter) XOR input
+    # through the identity enc(enc(x)) = x on the same library.
+    from concurrent.futures import ThreadPoolExecutor
+    g = gsc_chacha
+    assert g.init_verifier(0, golden_bytes("vk.chacha20"))
+    n = 4096
+    rnd = random.Random(2025)
+    recs = b"".join(rnd.randbytes(44) + rnd.getrandbits(32).to_bytes(4, "little") + rnd.randbytes(64) for _ in range(n))
+    ok, proofs, lens, cts = g.prove_raw(g.CHACHA20, recs, n)
+    assert ok == n and set(lens) == {164}
+    assert len({proofs[196 * k:196 * k + 164] for k in range(n)}) == n
+
+    def check(k):
+        rec = recs[112 * k:112 * (k + 1)]
+        signals = cts[64 * k:64 * k + 64] + rec[32:44] + rec[44:48] + rec[48:]
+        return g.verify({"cipher": "chacha20", "proof": base64.b64encode(proofs[196 * k:196 * k + 164]).decode(),
+                         "publicSignals": base64.b64encode(signals).decode()})
+    with ThreadPoolExecutor(16) as pool:
+        res = list(pool.map(check, range(n)))
+    assert all(res), [k for k, v in enumerate(res) if not v][:10]
+    # a proof does not verify for somebody else's statement
+    k = 17
+    rec = recs[112 * k:112 * (k + 1)]
+    wrong = cts[64 * (k + 1):64 * (k + 2)] + rec[32:44] + rec[44:48] + rec[48:]
+    assert not g.verify({"cipher": "chacha20", "proof": base64.b64encode(proofs[196 * k:196 * k + 164]).decode(), "publicSignals": base64.b64encode(wrong).decode()})
