@@ -174,7 +174,20 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
         } else {                                            // [hdr, loc, constraint, unk_wire, unk_coeff, L, R, O]
             fe va = v[0], vb = v[1], vc = v[2];
             const uint32_t loc = f1, cidx = f2, uw = f3, uc = f4;
-            fe ab = Fr::mul(va, vb);
+            // a*b: in these circuits the factors are mostly bits, or one of them is the constant 1 — a wave whose 64 proofs all
+            // fall in such a case replaces the 353-instruction product by selects (the solver is half VALU-bound at large batches)
+            fe ab;
+            {
+                const fe one = Fr::one();
+                const bool a0 = Fr::is_zero(va), a1 = Fr::eq(va, one), b0 = Fr::is_zero(vb), b1 = Fr::eq(vb, one);
+                if (__builtin_amdgcn_ballot_w64(!(b0 || b1)) == 0) {            // b is a bit everywhere: a*b = b ? a : 0
+#pragma unroll
+                    for (int k = 0; k < 8; k++) ab.l[k] = b1 ? va.l[k] : 0u;
+                } else if (__builtin_amdgcn_ballot_w64(!(a0 || a1)) == 0) {     // a is a bit everywhere
+#pragma unroll
+                    for (int k = 0; k < 8; k++) ab.l[k] = a1 ? vb.l[k] : 0u;
+                } else ab = Fr::mul(va, vb);
+            }
             if (loc == 0) bad = !Fr::eq(ab, vc);
             else {
                 fe wire;
@@ -187,7 +200,9 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
                     else { wire = Fr::zero(); bad = true; }     // the host selects HAS_DIV whenever the program divides
                     if (loc == 1) va = part; else vb = part;
                 }
-                wire = Fr::mul(wire, load_fe(a.coeff_inv + uc));
+                // divide by the unknown wire's coefficient; ids 1 and 3 are the constants 1 and -1 (checked at InitAlgorithm)
+                if (uc == 3) wire = Fr::neg(wire);
+                else if (uc != 1) wire = Fr::mul(wire, load_fe(a.coeff_inv + uc));
                 store_fe(a.W + (size_t)uw * batch + p, wire);
             }
             store_fe(a.A + (size_t)cidx * batch + p, va);
