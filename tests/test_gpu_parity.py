@@ -259,3 +259,22 @@ def test_bench_size_batch_every_proof_verifies(gsc_chacha):
     rec = recs[112 * k:112 * (k + 1)]
     wrong = cts[64 * (k + 1):64 * (k + 2)] + rec[32:44] + rec[44:48] + rec[48:]
     assert not g.verify({"cipher": "chacha20", "proof": base64.b64encode(proofs[196 * k:196 * k + 164]).decode(), "publicSignals": base64.b64encode(wrong).decode()})
+
+
+def test_repeated_batches_are_bit_identical(gsc_chacha):
+    # No atomics, no data-dependent scheduling: with (r, s) fixed, proving the same 2048 statements again — alone or embedded in a
+    # larger call that changes chunking and slice counts — must give the same bytes (catches races and uninitialised reads).
+    g = gsc_chacha
+    rnd = random.Random(31337)
+    n = 2048
+    recs = b"".join(rnd.randbytes(44) + rnd.getrandbits(32).to_bytes(4, "little") + rnd.randbytes(64) for _ in range(n))
+    g.set_deterministic_randomness(rnd.getrandbits(250), rnd.getrandbits(250), 0)
+    try:
+        ok1, p1, l1, c1 = g.prove_raw(g.CHACHA20, recs, n)
+        ok2, p2, l2, c2 = g.prove_raw(g.CHACHA20, recs, n)
+        ok3, p3, l3, c3 = g.prove_raw(g.CHACHA20, recs[:112 * 193], 193)          # a ragged prefix: different batch shape
+    finally:
+        g.set_deterministic_randomness(None)
+    assert ok1 == ok2 == n and ok3 == 193
+    assert p1 == p2 and c1 == c2
+    assert p3 == p1[:196 * 193] and c3 == c1[:64 * 193]
