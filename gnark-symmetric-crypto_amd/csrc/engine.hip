@@ -89,7 +89,7 @@ class AlgorithmImpl {
     std::mutex mu;
     hipStream_t stream = nullptr;   // init-time work; proving runs on the lanes' streams
     size_t table_bytes = 0;
-    std::vector<uint8_t> row_class;    // per scalar row (wire), predicted by calibrate(): 0 = always 0 or 1, else the largest bit length seen (255 = unknown)
+    std::vector<uint8_t> row_class;    // per scalar row (wire), predicted by calibrate(): 0 = always 0 or 1, 1 = also -1, else the largest bit length seen (255 = unknown)
     static constexpr int WIDE_BITS = 64;   // wires seen above this are given wide-digit tables
 
     // program
@@ -256,7 +256,7 @@ class AlgorithmImpl {
             std::vector<size_t> wide, bits, rest;
             for (size_t i = 0; i < n; i++) {
                 const int c0 = cls(i);
-                if (layout && c0 == 0) bits.push_back(i);
+                if (layout && c0 <= 1) bits.push_back(i);         // values in {-1, 0, 1}: grouped in eights
                 else if (layout && c0 != 255 && c0 > WIDE_BITS) wide.push_back(i);
                 else rest.push_back(i);
             }
@@ -292,7 +292,7 @@ class AlgorithmImpl {
         build(bases.p, n, c, set.nwin, set.table.p);
         if (set.nbit) {
             const size_t ng = set.nbit / 8;
-            set.sub.alloc(ng * 255); set.group_ok.alloc(ng);
+            set.sub.alloc(ng * MSM_GROUP_ENTRIES); set.group_ok.alloc(ng);
             table_bytes += set.sub.bytes();
             build_subset(bases.p + set.nwide, ng, set.sub.p, set.group_ok.p);
         }
@@ -304,8 +304,19 @@ class AlgorithmImpl {
         }
         HIP_CHECK(hipStreamSynchronize(stream));
     }
-    void build_subset(const G1Aff* b, size_t ng, G1Aff* t, uint8_t* ok) { DevBuf<G1Xyzz> sc(ng * 255); launch_build_subset_g1(b, ng, t, sc.p, ok, stream); HIP_CHECK(hipStreamSynchronize(stream)); }
-    void build_subset(const G2Aff* b, size_t ng, G2Aff* t, uint8_t* ok) { DevBuf<G2Xyzz> sc(ng * 255); launch_build_subset_g2(b, ng, t, sc.p, ok, stream); HIP_CHECK(hipStreamSynchronize(stream)); }
+    // group tables are built in chunks so that the projective scratch stays below ~2 GiB
+    void build_subset(const G1Aff* b, size_t ng, G1Aff* t, uint8_t* ok) {
+        size_t chunk = ((size_t)2 << 30) / (MSM_GROUP_ENTRIES * sizeof(G1Xyzz)); if (chunk > ng) chunk = ng;
+        DevBuf<G1Xyzz> sc(chunk * MSM_GROUP_ENTRIES);
+        for (size_t g0 = 0; g0 < ng; g0 += chunk) launch_build_subset_g1(b + 8 * g0, ng - g0 < chunk ? ng - g0 : chunk, t + g0 * MSM_GROUP_ENTRIES, sc.p, ok + g0, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    void build_subset(const G2Aff* b, size_t ng, G2Aff* t, uint8_t* ok) {
+        size_t chunk = ((size_t)2 << 30) / (MSM_GROUP_ENTRIES * sizeof(G2Xyzz)); if (chunk > ng) chunk = ng;
+        DevBuf<G2Xyzz> sc(chunk * MSM_GROUP_ENTRIES);
+        for (size_t g0 = 0; g0 < ng; g0 += chunk) launch_build_subset_g2(b + 8 * g0, ng - g0 < chunk ? ng - g0 : chunk, t + g0 * MSM_GROUP_ENTRIES, sc.p, ok + g0, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
 
     void init_key(const R1csFile& cs, const PkFile& key) {
         if (key.n_wires != n_wires) throw std::runtime_error("pk: wire count does not match the r1cs");

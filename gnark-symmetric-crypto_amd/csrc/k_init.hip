@@ -167,41 +167,51 @@ __global__ void k_build_table(const Aff<OldF>* bases, size_t row0, size_t nrows,
     }
 }
 
-// Subset-sum tables for groups of eight bases whose scalars are bits in (almost) every proof: entry m-1 of group g is
-// sum_{b in m} P_{8g+b}, m = 1..255, affine.  One thread per group; the sums are built in XYZZ with the exact addition
-// (T[m] = T[m without its lowest bit] + P[lowest bit]), parked in `scratch` (255 points per group), and converted with one
-// batch inversion like k_build_table.  A group where some subset sums to the point at infinity (equal or opposite bases)
-// cannot be tabulated in affine form: ok[g] = 0 and the MSM kernel treats its bases one by one.
+// Signed subset-sum tables for groups of eight bases whose scalars are -1, 0 or 1 in (almost) every proof: entry v-1 of group g is
+// sum_i t_i * P_{8g+i} for the balanced-ternary value v = sum_i t_i 3^i, v = 1 .. (3^8-1)/2, affine (negative v: the negated entry).
+// One thread per group.  With k the position of the leading digit (which is +1 for v > 0), v = 3^k + s with |s| <= (3^k-1)/2, so
+// T[v] = P_k + sign(s) T[|s|] only needs entries built before; sums are kept in XYZZ in `scratch` (MSM_GROUP_ENTRIES points per group)
+// and converted with one batch inversion like k_build_table.  A group where some signed subset sums to the point at infinity
+// (equal or opposite bases) cannot be tabulated in affine form: ok[g] = 0 and the MSM kernel treats its bases one by one.
 template <class F, class OldF>
 __global__ void k_build_subset(const Aff<OldF>* bases, size_t ngroups, fe* table, fe* scratch, uint8_t* ok) {
     using C = Curve9<F>;
     using E = typename F::E;
     constexpr int CW = F::WORDS;
+    constexpr uint32_t NT = MSM_GROUP_ENTRIES;
     const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g >= ngroups) return;
-    fe* out = table + g * 255 * (2 * CW);
-    fe* sc = scratch + g * 255 * (4 * CW);
+    fe* out = table + g * NT * (2 * CW);
+    fe* sc = scratch + g * NT * (4 * CW);
     bool good = true;
     E prefix = F::one();
-    for (uint32_t m = 1; m < 256; m++) {
-        const uint32_t low = (uint32_t)__ffs((int)m) - 1, rest = m & (m - 1);
-        const Aff9<F> P = base_to_fp29(bases + 8 * g + low);
-        Xyzz9<F> Em = rest ? C::template madd<true>(C::load_xyzz(sc + (rest - 1) * (4 * CW)), P) : C::from_aff(P);
-        if (Em.inf || F::is_zero(Em.zzz)) { good = false; Em = C::from_aff(P); }      // keep the arithmetic defined; the group is disabled
-        C::store_xyzz(sc + (m - 1) * (4 * CW), Em);
-        F::store(out + (m - 1) * (2 * CW), prefix);
-        prefix = F::mul(prefix, Em.zzz);
+    uint32_t k = 0, pw = 1;                       // leading digit position and 3^k
+    for (uint32_t v = 1; v <= NT; v++) {
+        while (v > (3 * pw - 1) / 2) { k++; pw *= 3; }
+        const int32_t s = (int32_t)v - (int32_t)pw;
+        const Aff9<F> P = base_to_fp29(bases + 8 * g + k);
+        Xyzz9<F> Ev;
+        if (s == 0) Ev = C::from_aff(P);
+        else {
+            Xyzz9<F> T = C::load_xyzz(sc + ((uint32_t)(s < 0 ? -s : s) - 1) * (4 * CW));
+            if (s < 0) T.y = F::neg(T.y);
+            Ev = C::template madd<true>(T, P);
+        }
+        if (Ev.inf || F::is_zero(Ev.zzz)) { good = false; Ev = C::from_aff(P); }      // keep the arithmetic defined; the group is disabled
+        C::store_xyzz(sc + (v - 1) * (4 * CW), Ev);
+        F::store(out + (v - 1) * (2 * CW), prefix);
+        prefix = F::mul(prefix, Ev.zzz);
     }
     ok[g] = good ? 1 : 0;
     E inv = F::inv(prefix);
-    for (uint32_t m = 255; m >= 1; m--) {
-        const Xyzz9<F> Em = C::load_xyzz(sc + (m - 1) * (4 * CW));
-        const E pre = F::load(out + (m - 1) * (2 * CW));
+    for (uint32_t v = NT; v >= 1; v--) {
+        const Xyzz9<F> Ev = C::load_xyzz(sc + (v - 1) * (4 * CW));
+        const E pre = F::load(out + (v - 1) * (2 * CW));
         const E izzz = F::mul(inv, pre);
-        inv = F::mul(inv, Em.zzz);
-        const E izz = F::mul(F::sqr(Em.zz), F::sqr(izzz));
-        Aff9<F> a; a.x = F::mul(Em.x, izz); a.y = F::mul(Em.y, izzz);
-        C::store_aff(out + (m - 1) * (2 * CW), a);
+        inv = F::mul(inv, Ev.zzz);
+        const E izz = F::mul(F::sqr(Ev.zz), F::sqr(izzz));
+        Aff9<F> a; a.x = F::mul(Ev.x, izz); a.y = F::mul(Ev.y, izzz);
+        C::store_aff(out + (v - 1) * (2 * CW), a);
     }
 }
 

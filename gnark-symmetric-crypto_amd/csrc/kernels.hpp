@@ -63,11 +63,12 @@ void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStr
 // *flag |= 1 if some OP_COUNT table's index column is not 0,1,2,... (InitAlgorithm-time validation)
 void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s);
 
+constexpr uint32_t MSM_GROUP_ENTRIES = 3280;      // (3^8 - 1) / 2
 void launch_build_subset_g1(const G1Aff* bases, size_t ngroups, G1Aff* table, G1Xyzz* scratch, uint8_t* ok, hipStream_t s);
 void launch_build_subset_g2(const G2Aff* bases, size_t ngroups, G2Aff* table, G2Xyzz* scratch, uint8_t* ok, hipStream_t s);
 
 // Calibration: cls[w] = 0 if wire w is 0 or 1 in every accepted proof of the batch (status == 0xFFFFFFFF), otherwise the largest bit
-// length of its sign-normalised value (1..254).  W: [n_wires][batch] Montgomery.
+// length of its sign-normalised value (1 = the wire also takes -1, .. 254).  W: [n_wires][batch] Montgomery.
 void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint32_t* status, uint8_t* cls, hipStream_t s);
 
 // ---- quotient polynomial (k_ntt.hip) ----
@@ -88,8 +89,9 @@ struct MsmArgs {
     void* partial;                 // G1Xyzz / G2Xyzz [nslices][batch]
     // Layout of a wire set, predicted at InitAlgorithm (never trusted for correctness):
     //   bases [0, nwide)            full-width scalars: a second digit table with wider digits (table2, c2, nwin2; base index k)
-    //   bases [nwide, nwide + nbit) scalars that are 0 or 1 in nearly every proof (nwide, nbit multiples of 8): group g = bases
-    //                               nwide+8g .. +7 has a subset-sum table sub[g][m-1] = sum_{b in m} base (255 affine entries), group_ok[g] != 0
+    //   bases [nwide, nwide + nbit) scalars that are -1, 0 or 1 in nearly every proof (nwide, nbit multiples of 8): group g = bases
+    //                               nwide+8g .. +7 has a table of signed subset sums sub[g][v-1] = sum_i t_i * base_i for the balanced-ternary
+    //                               value v = sum_i t_i 3^i > 0 (MSM_GROUP_ENTRIES affine entries; v < 0 is the negated entry), group_ok[g] != 0
     //   the rest                    everything else, through `table`
     size_t nbit; const void* sub; const uint8_t* group_ok;
     size_t nwide; const void* table2; int c2, nwin2;

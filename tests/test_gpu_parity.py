@@ -207,7 +207,8 @@ print("DIGEST", hashlib.sha256(proofs + cts).hexdigest())
 def _digest(env_extra, algo=0, pk_path=None):
     import subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="8", **env_extra)
+    # small tables: these child processes share the device with the algorithms the test session already holds (~170 GB)
+    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_WIDE_TABLE_GB="4", **env_extra)
     args = [sys.executable, "-c", _OPTIONS_SCRIPT, ROOT, str(algo)] + ([pk_path] if pk_path else [])
     out = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
