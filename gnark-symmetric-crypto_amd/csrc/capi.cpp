@@ -286,14 +286,27 @@ struct Prove_return ProveBatch(GoSlice params) {
             try { ok.push_back(prepare(root.items[i])); where.push_back(i); }
             catch (const GoPanic& g) { results[i] = g.json; }
         }
-        for (int c = 0; c < 3; c++) {                              // one device batch per algorithm
-            std::vector<ProofRequest> reqs; std::vector<size_t> idx;
-            for (size_t k = 0; k < ok.size(); k++) if (ok[k].cipher == c) { reqs.push_back(ok[k].req); idx.push_back(where[k]); }
-            if (reqs.empty()) continue;
-            std::vector<ProofResult> res(reqs.size());
-            lookup(c)->prove_batch(reqs.data(), reqs.size(), res.data());
-            for (size_t k = 0; k < reqs.size(); k++) results[idx[k]] = res[k].status ? std::string("{}") : success_json(res[k], reqs[k].ciphertext);
-        }
+        // one device batch per algorithm; the algorithms have their own streams and buffers, so their batches run concurrently
+        // (the solver levels and the commitment round trip of one hide under the MSMs of another)
+        std::exception_ptr err; std::mutex err_mu;
+        auto run = [&](int c) {
+            try {
+                std::vector<ProofRequest> reqs; std::vector<size_t> idx;
+                for (size_t k = 0; k < ok.size(); k++) if (ok[k].cipher == c) { reqs.push_back(ok[k].req); idx.push_back(where[k]); }
+                if (reqs.empty()) return;
+                std::vector<ProofResult> res(reqs.size());
+                lookup(c)->prove_batch(reqs.data(), reqs.size(), res.data());
+                for (size_t k = 0; k < reqs.size(); k++) results[idx[k]] = res[k].status ? std::string("{}") : success_json(res[k], reqs[k].ciphertext);
+            } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+        };
+        bool present[3] = {false, false, false};
+        for (const Prepared& p : ok) present[p.cipher] = true;
+        std::vector<std::thread> th;
+        int first = -1;
+        for (int c = 0; c < 3; c++) if (present[c]) { if (first < 0) first = c; else th.emplace_back(run, c); }
+        if (first >= 0) run(first);
+        for (auto& t : th) t.join();
+        if (err) std::rethrow_exception(err);
         out = "[";
         for (size_t i = 0; i < n; i++) { if (i) out += ","; out += results[i]; }
         out += "]";
