@@ -38,20 +38,6 @@ __device__ __forceinline__ bool sign_normalise(fe& s) {
     return gt;
 }
 
-// limb i of s, i wave-uniform but not a compile-time constant: a select chain keeps s in registers
-// (indexing s.l[] dynamically would push the scalar into scratch memory)
-__device__ __forceinline__ uint32_t limb_at(const fe& s, uint32_t i) {
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) r = i == (uint32_t)k ? s.l[k] : r;
-    return r;
-}
-__device__ __forceinline__ uint32_t bits_at(const fe& s, uint32_t pos, uint32_t c) {
-    const uint32_t w = pos >> 5, sh = pos & 31;
-    const uint64_t v = (uint64_t)limb_at(s, w) | ((uint64_t)limb_at(s, w + 1) << 32);
-    return (uint32_t)(v >> sh) & ((1u << c) - 1);
-}
-
 // raw memory image of one affine table entry (2 * WORDS field elements), kept packed until it is consumed
 template <class F> struct RawAff { fe w[2 * F::WORDS]; };
 template <class F> __device__ __forceinline__ RawAff<F> load_raw(const fe* p) {
@@ -147,8 +133,12 @@ __device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0
         uint32_t need = top < 0 ? 0u : (uint32_t)top / c + 2u;
         if (need > nwin) need = nwin;
         uint32_t carry = 0;
+        const uint32_t cmask = (1u << c) - 1;
         for (uint32_t j = 0; j < need; j++) {
-            uint32_t raw = bits_at(s, j * c, c) + carry;
+            uint32_t raw = (s.l[0] & cmask) + carry;        // the scalar is shifted down one digit per step: no variable limb indexing
+#pragma unroll
+            for (int i = 0; i < 7; i++) s.l[i] = __builtin_amdgcn_alignbit(s.l[i + 1], s.l[i], c);
+            s.l[7] >>= c;
             bool dneg = false;
             if (raw > D) { raw = (1u << c) - raw; dneg = true; carry = 1; } else carry = 0;
             if (raw) {
