@@ -55,6 +55,7 @@ def lib():
         L.ProveBatch.argtypes = [GoSlice]
         L.gsc_prove_raw.restype = C.c_longlong
         L.gsc_prove_raw.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gsc_set_deterministic_randomness.restype = C.c_int
         L.gsc_set_deterministic_randomness.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
         L.gsc_debug_prove.restype = C.c_longlong
         L.gsc_debug_prove.argtypes = [GoSlice]
@@ -129,11 +130,14 @@ def prove_raw_into(cipher: int, records: bytes, n: int, proofs, lens, cts) -> in
 
 
 def set_deterministic_randomness(r=None, s=None, mask=0):
-    """TEST HOOK: fix (r, s, mask) as integers; None restores the CSPRNG."""
+    """TEST HOOK: fix (r, s, mask) as integers; None restores the CSPRNG.  Needs GSC_ENABLE_TEST_HOOKS=1 in the environment
+    before the library is loaded."""
     if r is None:
-        lib().gsc_set_deterministic_randomness(None, None, None)
+        rc = lib().gsc_set_deterministic_randomness(None, None, None)
     else:
-        lib().gsc_set_deterministic_randomness(int(r).to_bytes(32, "big"), int(s).to_bytes(32, "big"), int(mask).to_bytes(32, "big"))
+        rc = lib().gsc_set_deterministic_randomness(int(r).to_bytes(32, "big"), int(s).to_bytes(32, "big"), int(mask).to_bytes(32, "big"))
+    if rc != 0:
+        raise RuntimeError("test hooks are disabled: set GSC_ENABLE_TEST_HOOKS=1 before loading libprove.so")
 
 
 def debug_prove(params: dict):

@@ -9,6 +9,7 @@
 #include "host_ciphers.hpp"
 #include "json.hpp"
 #include <sys/random.h>
+#include <cerrno>
 #include <condition_variable>
 #include <deque>
 #include <thread>
@@ -74,8 +75,18 @@ class Batcher {
 std::mutex g_mu;
 std::unique_ptr<Algorithm> g_algo[3];
 std::unique_ptr<Batcher> g_batcher[3];     // declared after g_algo: destroyed first
-bool g_fixed_rand = false; uint8_t g_r[32], g_s[32], g_mask[32];   // little-endian canonical
+bool g_fixed_rand = false; uint8_t g_r[32], g_s[32], g_mask[32];   // little-endian canonical; written under g_mu, read by fill_randomness under g_mu
 DebugVectors g_debug;
+// The gsc_debug_* entry points and gsc_set_deterministic_randomness exist for the parity tests only: fixing (r, s, mask) removes
+// zero-knowledge for every caller of the process.  They refuse to work unless the process was started with
+// GSC_ENABLE_TEST_HOOKS=1; the variable is read ONCE, when the library is loaded, so code running inside the host cannot
+// switch them on later.
+const bool g_test_hooks = [] { const char* e = getenv("GSC_ENABLE_TEST_HOOKS"); return e && e[0] == '1' && e[1] == 0; }();
+bool hooks_refused(const char* what) {
+    if (g_test_hooks) return false;
+    printf("%s refused: test hooks are disabled (start the process with GSC_ENABLE_TEST_HOOKS=1)\n", what);
+    return true;
+}
 
 // Fr modulus, big-endian
 const uint8_t kFrModBE[32] = {0x30, 0x64, 0x4e, 0x72, 0xe1, 0x31, 0xa0, 0x29, 0xb8, 0x50, 0x45, 0xb6, 0x81, 0x81, 0x58, 0x5d,
@@ -88,7 +99,12 @@ void csprng_bytes(uint8_t* out, size_t n) {
     while (n) {
         if (!have) {
             size_t got = 0;
-            while (got < sizeof pool) { ssize_t k = getrandom(pool + got, sizeof pool - got, 0); if (k > 0) got += (size_t)k; }
+            while (got < sizeof pool) {
+                const ssize_t k = getrandom(pool + got, sizeof pool - got, 0);
+                if (k > 0) got += (size_t)k;
+                else if (k < 0 && errno == EINTR) continue;
+                else throw std::runtime_error(std::string("getrandom failed: ") + strerror(errno));   // e.g. ENOSYS under seccomp: fail the request, never spin or fall back
+            }
             have = sizeof pool;
         }
         const size_t take = n < have ? n : have;
@@ -195,8 +211,11 @@ ProofRequest make_request(int cipher, const Decoded& d) {
     return q;
 }
 void fill_randomness(ProofRequest& q) {
-    if (g_fixed_rand) { memcpy(q.r, g_r, 32); memcpy(q.s, g_s, 32); memcpy(q.mask, g_mask, 32); }
-    else { random_fr_le(q.r); random_fr_le(q.s); random_fr_le(q.mask); }
+    if (g_test_hooks) {      // the fixed values can only ever be set in a test process
+        std::lock_guard<std::mutex> l(g_mu);
+        if (g_fixed_rand) { memcpy(q.r, g_r, 32); memcpy(q.s, g_s, 32); memcpy(q.mask, g_mask, 32); return; }
+    }
+    random_fr_le(q.r); random_fr_le(q.s); random_fr_le(q.mask);
 }
 
 Algorithm* lookup(int cipher) { std::lock_guard<std::mutex> l(g_mu); return g_algo[cipher].get(); }
@@ -347,19 +366,23 @@ long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t
     } catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
 }
 
-void gsc_set_deterministic_randomness(const uint8_t* r_be32, const uint8_t* s_be32, const uint8_t* mask_be32) {
+int gsc_set_deterministic_randomness(const uint8_t* r_be32, const uint8_t* s_be32, const uint8_t* mask_be32) {
+    if (hooks_refused("gsc_set_deterministic_randomness")) return -1;
     std::lock_guard<std::mutex> l(g_mu);
-    if (!r_be32 || !s_be32) { g_fixed_rand = false; return; }
+    if (!r_be32 || !s_be32) { g_fixed_rand = false; return 0; }
     for (int i = 0; i < 32; i++) { g_r[i] = r_be32[31 - i]; g_s[i] = s_be32[31 - i]; g_mask[i] = mask_be32 ? mask_be32[31 - i] : 0; }
     g_fixed_rand = true;
+    return 0;
 }
 
 long long gsc_debug_prove(GoSlice params) {
+    if (hooks_refused("gsc_debug_prove")) return -1;
     g_debug = DebugVectors();
     std::string r = prove_one_json((const char*)params.data, params.len > 0 ? (size_t)params.len : 0, &g_debug);
     return r.find("\"proof\"") != std::string::npos ? 0 : -1;
 }
 long long gsc_debug_vector(int which, uint8_t* out, size_t cap) {
+    if (hooks_refused("gsc_debug_vector")) return -1;
     const std::vector<uint8_t>* v = which == 0 ? &g_debug.W : which == 1 ? &g_debug.A : which == 2 ? &g_debug.B : which == 3 ? &g_debug.C : which == 4 ? &g_debug.H : nullptr;
     if (!v || v->empty()) return -1;
     if (out) memcpy(out, v->data(), cap < v->size() ? cap : v->size());
@@ -367,12 +390,13 @@ long long gsc_debug_vector(int which, uint8_t* out, size_t cap) {
 }
 
 int gsc_debug_field_ops(int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int chain) {
+    if (hooks_refused("gsc_debug_field_ops")) return -1;
     try { debug_field_ops(config_from_env().device, field, op, a, b, out, n, chain); return 0; }
     catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
 }
 
 long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t* abc_be, size_t m, uint8_t* h_out, size_t cap) {
-    if (algorithmID > 2) return -1;
+    if (hooks_refused("gsc_debug_compute_h") || algorithmID > 2) return -1;
     Algorithm* a = lookup(algorithmID); if (!a) return -1;
     if (!h_out) return (long long)a->domain_size();
     if (cap < a->domain_size() * 64 * 32) return -1;

@@ -220,6 +220,7 @@ class AlgorithmImpl {
         }
         DevBuf<uint8_t> d_cls(n_wires);
         launch_classify_wires(d_W.p, n_wires, B, d_status.p, d_cls.p, stream);
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(row_class.data(), d_cls.p, n_wires, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
@@ -302,6 +303,7 @@ class AlgorithmImpl {
             table_bytes += set.table2.bytes();
             build(bases.p, set.nwide, set.c2, set.nwin2, set.table2.p);
         }
+        HIP_CHECK(hipGetLastError());      // table-build launches
         HIP_CHECK(hipStreamSynchronize(stream));
     }
     // group tables are built in chunks so that the projective scratch stays below ~2 GiB
@@ -321,7 +323,8 @@ class AlgorithmImpl {
     void init_key(const R1csFile& cs, const PkFile& key) {
         if (key.n_wires != n_wires) throw std::runtime_error("pk: wire count does not match the r1cs");
         domain_n = key.domain_n; L = 0; while (((size_t)1 << L) < domain_n) L++;
-        if (domain_n < n_constraints || L < 4 || L > 24) throw std::runtime_error("pk: domain too small for the constraint system");
+        if (domain_n < n_constraints || domain_n != (size_t)1 << L) throw std::runtime_error("pk: domain too small for the constraint system");
+        if (L < NTT_MIN_LOG2 || L > NTT_MAX_LOG2) throw std::runtime_error("pk: unsupported domain size 2^" + std::to_string(L) + " (the quotient kernels cover 2^15 .. 2^17: ChaCha20-V3 and AES-V2)");
         if (cs.has_commitment != key.has_commitment_key) throw std::runtime_error("pk: commitment keys do not match the r1cs");
         // NTT constants
         {
@@ -332,6 +335,7 @@ class AlgorithmImpl {
             launch_fr_from_be(d_be.p, dom.p, 5, stream);
             tw_fwd.alloc(domain_n / 2 * 12); tw_inv.alloc(domain_n / 2 * 12); scale_mid.alloc(domain_n); scale_out.alloc(domain_n); qr.alloc((2 * NTT_QMAX + 1) * 12);
             launch_ntt_constants(dom.p, dom.p + 1, dom.p + 2, dom.p + 3, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, stream);
+            HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipStreamSynchronize(stream));
         }
         auto cat = [](std::vector<uint8_t> a, std::initializer_list<const std::vector<uint8_t>*> more) { for (auto* m : more) a.insert(a.end(), m->begin(), m->end()); return a; };
@@ -506,7 +510,8 @@ class AlgorithmImpl {
         }
         // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
         NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
-        launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream);
+        HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
+        HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream));
         HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
         if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
         // 3. MSMs
@@ -519,9 +524,11 @@ class AlgorithmImpl {
             run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);
             launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
         }
+        HIP_CHECK(hipGetLastError());      // MSM launches
         HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
         // 4. assembly
         launch_finalize(ln.d_sumA.p, ln.d_sumB1.p, ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.stream);
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
         std::vector<uint8_t> h_out(256 * B), h_flags(ln.d_flags.n); std::vector<uint32_t> h_status(B);
         HIP_CHECK(hipMemcpyAsync(h_out.data(), ln.d_out.p, h_out.size(), hipMemcpyDeviceToHost, ln.stream));
@@ -613,7 +620,7 @@ void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out)
     launch_fr_from_be(d_be.p + cnt * 32, ln.d_B.p, cnt, ln.stream);
     launch_fr_from_be(d_be.p + 2 * cnt * 32, ln.d_C.p, cnt, ln.stream);
     NttPlan plan{a.L, a.tw_fwd.p, a.tw_inv.p, a.scale_mid.p, a.scale_out.p, a.dom.p + 5, a.qr.p};
-    launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, m, B, ln.stream);
+    HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, m, B, ln.stream));
     HIP_CHECK(hipMemcpyAsync(h_out, ln.d_A.p, a.domain_n * B * 32, hipMemcpyDeviceToHost, ln.stream));
     HIP_CHECK(hipStreamSynchronize(ln.stream));
 }

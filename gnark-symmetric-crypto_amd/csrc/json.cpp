@@ -48,7 +48,7 @@ struct Parser {
         }
     }
     JsonValue value() {
-        if (++depth > 10000) fail("exceeded max depth");
+        if (++depth > JSON_MAX_DEPTH) fail("exceeded max depth");
         ws();
         if (i >= n) fail("unexpected end of JSON input");
         JsonValue v; char c = d[i]; v.start = i;

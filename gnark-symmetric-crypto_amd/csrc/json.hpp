@@ -25,6 +25,9 @@ struct JsonSyntaxError : std::runtime_error {
     JsonSyntaxError(const std::string& m, size_t off) : std::runtime_error(m), offset(off) {}
 };
 
+// Nesting limit of the recursive-descent reader.  InputParams needs 2 levels and a ProveBatch array 3; encoding/json's own
+// limit (10000) would need megabytes of native stack, which FFI worker threads (musl, node workers) do not have.
+constexpr int JSON_MAX_DEPTH = 64;
 JsonValue json_parse(const char* data, size_t len);      // throws JsonSyntaxError
 std::string json_quote(const std::string& s);            // Go-compatible string escaping (HTML-safe escapes included)
 

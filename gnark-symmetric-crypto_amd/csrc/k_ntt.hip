@@ -291,19 +291,23 @@ __global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, si
 
 }  // namespace
 
-void launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s) {
+hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s) {
     const int L = p.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
+    if (L < NTT_MIN_LOG2 || L > NTT_MAX_LOG2 || batch % P) return hipErrorInvalidValue;      // block sizes / launch bounds below assume this range
     const unsigned G = 1u << Lhi, Cn = 1u << Llo;
     const unsigned pb = (unsigned)(batch / P);
     const size_t lds_s = (size_t)G * P * 36, lds_c = (size_t)Cn * P * 36;      // nine 32-bit limb planes per element
-    if (lds_s > 65536) {       // 2^17 domains (AES-V2): 72 KiB tiles need the opt-in LDS limit (a CU has 160 KiB)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_dif_strided), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pointwise_strided), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-    }
+    hipError_t e = hipSuccess;
+    auto opt_in = [&](const void* f, size_t lds) { if (e == hipSuccess && lds > 65536) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
+    // 2^17 domains (AES-V2): 72 KiB tiles need the opt-in LDS limit (a CU has 160 KiB)
+    opt_in(reinterpret_cast<const void*>(k_ntt_dif_strided), lds_s); opt_in(reinterpret_cast<const void*>(k_ntt_pointwise_strided), lds_s);
+    opt_in(reinterpret_cast<const void*>(k_ntt_mid_contig), lds_c); opt_in(reinterpret_cast<const void*>(k_ntt_final_contig), lds_c);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch);
     hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 3), dim3(Cn / 4 * P), lds_c, s, p, a, b, c, batch);
     hipLaunchKernelGGL(k_ntt_pointwise_strided, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, c, batch);
     hipLaunchKernelGGL(k_ntt_final_contig, dim3(G, pb, 1), dim3(Cn / 4 * P), lds_c, s, p, a, batch);
+    return hipGetLastError();
 }
 
 }  // namespace gsc

@@ -76,7 +76,10 @@ struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* 
 constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_QMAX .. NTT_QMAX (range reduction by the top limb)
 // a,b,c: [n][batch] Montgomery, first m rows valid (rows >= m are treated as zero and need not be initialised).
 // On return `a` holds h in canonical form: a[pos] = h_{bitrev(pos)} — the order pk.G1.Z is stored in.
-void launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s);
+// Domains the four kernels are written (and tested) for: workgroups of 2^ceil(L/2) and 2^floor(L/2) threads within their launch bounds.
+constexpr int NTT_MIN_LOG2 = 15, NTT_MAX_LOG2 = 17;
+// Returns the first launch-configuration error (nothing is launched when the domain is unsupported).
+hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s);
 
 // ---- multi-scalar multiplication (k_msm.hip) ----
 // partial[slice * batch + proof] = sum over bases k in slice of scalar[rows[k]][proof] * base_k

@@ -220,6 +220,37 @@ bool g1_decode(const uint8_t* b, G1& p) {
     if ((flag == 0xC0) != y.lex_large()) y = y.neg();
     p.y = y; p.inf = false; return true;
 }
+// The twist E'(Fp2) has order r * (2p - r): a point that satisfies the curve equation need not lie in the r-torsion subgroup G2.
+// gnark-crypto's decoder rejects such points (G2Affine.SetBytes -> IsInSubGroup) and so does groth16.Verify (proof.isValid()),
+// so the drop-in must too.  Plain test [r]Q == O in Jacobian coordinates (381 group operations, no inversion).
+bool g2_in_subgroup(const G2& q) {
+    if (q.inf) return true;
+    Fp2 X = Fp2::zero(), Y = Fp2::zero(), Z = Fp2::zero(); bool inf = true;
+    const U256 r = Fr::MOD;
+    for (int i = 255; i >= 0; i--) {
+        if (!inf) {      // dbl-2009-l (a = 0)
+            const Fp2 A = X.sq(), B = Y.sq(), C = B.sq(); Fp2 D = (X + B).sq() - A - C; D = D + D;
+            const Fp2 E = A + A + A, F = E.sq(), Z3 = (Y * Z) + (Y * Z); Fp2 C8 = C + C; C8 = C8 + C8; C8 = C8 + C8;
+            X = F - D - D; Y = E * (D - X) - C8; Z = Z3;
+            if (Z.is_zero()) inf = true;
+        }
+        if (!((r.w[i / 64] >> (i % 64)) & 1)) continue;
+        if (inf) { X = q.x; Y = q.y; Z = Fp2::one(); inf = false; continue; }
+        // madd-2007-bl
+        const Fp2 Z1Z1 = Z.sq(), U2 = q.x * Z1Z1, S2 = q.y * Z * Z1Z1, H = U2 - X; Fp2 rr = S2 - Y; rr = rr + rr;
+        if (H.is_zero()) {
+            if (!rr.is_zero()) { inf = true; continue; }
+            const Fp2 A = X.sq(), B = Y.sq(), C = B.sq(); Fp2 D = (X + B).sq() - A - C; D = D + D;      // accumulator == Q: double
+            const Fp2 E = A + A + A, F = E.sq(), Z3 = (Y * Z) + (Y * Z); Fp2 C8 = C + C; C8 = C8 + C8; C8 = C8 + C8;
+            X = F - D - D; Y = E * (D - X) - C8; Z = Z3; continue;
+        }
+        const Fp2 HH = H.sq(); Fp2 I = HH + HH; I = I + I; const Fp2 J = H * I, V = X * I;
+        const Fp2 X3 = rr.sq() - J - V - V; Fp2 YJ = Y * J; YJ = YJ + YJ;
+        const Fp2 Y3 = rr * (V - X3) - YJ, Z3 = (Z + H).sq() - Z1Z1 - HH;
+        X = X3; Y = Y3; Z = Z3;
+    }
+    return inf;
+}
 bool g2_decode(const uint8_t* b, G2& p) {
     const uint8_t flag = b[0] & 0xC0; uint8_t xb[32]; memcpy(xb, b, 32); xb[0] &= 0x3F;
     if (flag == 0x40) {
@@ -230,7 +261,8 @@ bool g2_decode(const uint8_t* b, G2& p) {
     if (!Fp::from_be(xb, p.x.b) || !Fp::from_be(b + 32, p.x.a)) return false;
     Fp2 y; if (!fp2_sqrt(p.x.sq() * p.x + K().twist_b, y)) return false;
     if ((flag == 0xC0) != y.lex_large()) y = y.neg();
-    p.y = y; p.inf = false; return true;
+    p.y = y; p.inf = false;
+    return g2_in_subgroup(p);
 }
 
 // Fp12 = Fp2[w]/(w^6 - xi)

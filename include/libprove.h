@@ -51,10 +51,15 @@ extern struct Prove_return ProveBatch(GoSlice params);
  * ciphertexts: n x 64 bytes.  Returns the number of proofs produced, or -1 if the algorithm is not initialised. */
 extern long long gsc_prove_raw(GoUint8 cipher, const uint8_t *inputs, size_t n, uint8_t *proofs, uint32_t *proof_lens, uint8_t *ciphertexts);
 
+/* TEST HOOKS.  gsc_set_deterministic_randomness and every gsc_debug_* function below refuse to work (return -1, message on
+ * stdout) unless the process was started with GSC_ENABLE_TEST_HOOKS=1 in its environment; the variable is read once, when the
+ * library is loaded.  A production host never sets it: fixed prover randomness voids zero-knowledge for the whole process. */
+
 /* TEST HOOK: fixes the prover randomness (r, s, AES commitment mask; 32-byte big-endian, < Fr modulus) for every
  * subsequent proof of this process; pass NULLs to return to the OS CSPRNG (the default).  With it fixed the proof is a
- * deterministic function of the inputs, which is what byte-level parity with gnark is defined on. */
-extern void gsc_set_deterministic_randomness(const uint8_t *r_be32, const uint8_t *s_be32, const uint8_t *mask_be32);
+ * deterministic function of the inputs, which is what byte-level parity with gnark is defined on.
+ * Returns 0, or -1 when test hooks are disabled. */
+extern int gsc_set_deterministic_randomness(const uint8_t *r_be32, const uint8_t *s_be32, const uint8_t *mask_be32);
 
 /* TEST HOOK: runs one proof and copies the intermediate vectors of the device pipeline for parity tests.
  * which: 0 W (n_wires), 1 A, 2 B, 3 C (n_constraints), 4 h (domain size; element k = h_{bitrev(k)}).

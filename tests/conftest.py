@@ -5,6 +5,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["GSC_ENABLE_TEST_HOOKS"] = "1"      # read once by libprove.so when it is loaded (include/libprove.h, TEST HOOKS)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -34,6 +34,45 @@ def test_product_never_links_the_oracle(gsc):
                 assert "liboracle" not in src and "from oracle" not in src and "import oracle" not in src, f
 
 
+def test_test_hooks_refuse_without_the_environment_opt_in(gsc):
+    # a production host never sets GSC_ENABLE_TEST_HOOKS: fixing (r, s, mask) or reading intermediates must be impossible there
+    code = (
+        "import os, sys, ctypes as C; os.environ.pop('GSC_ENABLE_TEST_HOOKS', None)\n"
+        "sys.path.insert(0, %r); import gsc_loader; g = gsc_loader.load(); L = g.lib()\n"
+        "one = (1).to_bytes(32, 'big')\n"
+        "assert L.gsc_set_deterministic_randomness(one, one, one) == -1\n"
+        "assert L.gsc_debug_vector(0, None, 0) == -1\n"
+        "assert L.gsc_debug_field_ops(0, 0, one, one, C.create_string_buffer(32), 1, 1) == -1\n"
+        "s, keep = g._slice(b'{}'); assert L.gsc_debug_prove(s) == -1\n"
+        "L.gsc_debug_compute_h.restype = C.c_longlong; assert L.gsc_debug_compute_h(0, None, 0, None, 0) == -1\n"
+        "try:\n    g.set_deterministic_randomness(1, 1)\nexcept RuntimeError: print('refused')\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "GSC_ENABLE_TEST_HOOKS"}
+    out = subprocess.check_output([sys.executable, "-c", code], env=env).decode()
+    assert "refused\n" in out and out.count("test hooks are disabled") == 6      # (C stdio and Python flush in their own order)
+    assert gsc.lib().gsc_set_deterministic_randomness(None, None, None) == 0      # this process opted in (conftest.py)
+
+
+def test_deeply_nested_json_is_an_error_not_a_stack_overflow(gsc):
+    # 20 KB of '[' used to overflow a 1 MiB thread stack inside the recursive-descent parser (and the JsonValue destructor)
+    import threading
+    res = {}
+
+    def work():
+        for depth in (65, 9999, 200000):
+            doc = b"[" * depth + b"]" * depth
+            res[depth] = json.loads(gsc.prove(doc))
+            res[("obj", depth)] = json.loads(gsc.prove(b'{"a":' * depth + b"1" + b"}" * depth))
+        res["ok"] = json.loads(gsc.prove(b"[" * 64 + b"]" * 64))
+    old = threading.stack_size(256 * 1024)
+    try:
+        t = threading.Thread(target=work); t.start(); t.join()
+    finally:
+        threading.stack_size(old)
+    for depth in (65, 9999, 200000):
+        assert res[depth] == {"Offset": 64} and res[("obj", depth)] == {"Offset": 5 * 64}      # json.SyntaxError-shaped: "exceeded max depth"
+    assert res["ok"]["Value"] == "array"             # 64 levels still parse (and are then a type error, like any array)
+
+
 def test_without_gpu_init_fails_loudly_and_prove_reports_uninitialised(gsc, capfd):
     import torch
     if torch.cuda.is_available():

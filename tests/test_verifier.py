@@ -55,6 +55,58 @@ def test_malformed_inputs_are_false_never_a_crash(verifier):
     assert not verifier.init_verifier(0, b"\x00" * 50) and not verifier.init_verifier(9, golden_bytes("vk.chacha20"))
 
 
+def _twist_point_outside_g2():
+    """A point of E'(Fp2): y^2 = x^3 + 3/(9+u) that is NOT in the r-torsion subgroup (a random twist point is in G2 with
+    probability r / #E' ~ 2^-254), compressed the gnark-crypto way (X.A1 | X.A0, flags from y)."""
+    P = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+    mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+    inv82 = pow(82, -1, P); bt = (27 * inv82 % P, -3 * inv82 % P)
+
+    def sqrt_fp(a):
+        s = pow(a, (P + 1) // 4, P)
+        return s if s * s % P == a % P else None
+
+    def sqrt_fp2(a):      # norm method, p = 3 mod 4
+        if a[1] == 0:
+            s = sqrt_fp(a[0])
+            if s is not None:
+                return (s, 0)
+            s = sqrt_fp(-a[0] % P)
+            return None if s is None else (0, s)
+        n = sqrt_fp((a[0] * a[0] + a[1] * a[1]) % P)
+        if n is None:
+            return None
+        for t in ((a[0] + n) * pow(2, -1, P) % P, (a[0] - n) * pow(2, -1, P) % P):
+            x0 = sqrt_fp(t)
+            if x0:
+                x = (x0, a[1] * pow(2 * x0, -1, P) % P)
+                if mul(x, x) == (a[0] % P, a[1] % P):
+                    return x
+        return None
+    k = 1
+    while True:
+        x = (k, 1); x3 = mul(mul(x, x), x); y = sqrt_fp2(((x3[0] + bt[0]) % P, (x3[1] + bt[1]) % P))
+        if y is not None:
+            break
+        k += 1
+    large = (y[1] > (P - 1) // 2) if y[1] else (y[0] > (P - 1) // 2)
+    enc = bytearray(x[1].to_bytes(32, "big") + x[0].to_bytes(32, "big")); enc[0] |= 0xC0 if large else 0x80
+    return bytes(enc)
+
+
+def test_g2_points_outside_the_r_torsion_subgroup_are_rejected(gsc):
+    # gnark-crypto's decoder checks subgroup membership (and so does groth16.Verify); a curve-equation check alone accepts
+    # twist points of the cofactor subgroup.  A verifying key with such a gamma must not load; a proof with such a Bs is false.
+    vk = bytearray(golden_bytes("vk.chacha20")); bad = _twist_point_outside_g2()
+    assert gsc.init_verifier(0, bytes(vk))
+    vk[128:192] = bad                                  # alpha(32) beta1(32) beta2(64) | gamma2 at 128
+    assert not gsc.init_verifier(0, bytes(vk))
+    assert gsc.init_verifier(0, golden_bytes("vk.chacha20"))
+    proof = bytearray(bytes.fromhex(KAT["proofs"][(0, 0)])); proof[32:96] = bad
+    sig = _sig(KAT["ciphertext"], KAT["nonce"], KAT["counter"], KAT["input"])
+    assert not gsc.verify({"cipher": "chacha20", "proof": bytes(proof), "publicSignals": sig})
+
+
 def test_agrees_with_oracle_on_random_chacha_proofs(verifier, oracle, chacha_oracle):
     cs, pk, vk = chacha_oracle
     rnd = random.Random(31)
