@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — Groth16 proofs/sec for ChaCha20-V3 single 64-byte blocks on N MI355X (BASELINE.json metric).
+"""bench.py — Groth16 proofs/sec on N MI355X (BASELINE.json metric), through the libprove C-ABI.
 
-A "step" is one pass of the hot path (witness -> quotient NTTs -> 5 MSMs -> proof assembly) over one batch
-of `--batch` synthetic, independent statements per GPU, through the C-ABI (gsc_prove_raw: the binary twin of
-Prove; no JSON on the timed path).  Independent proofs shard across ranks (one process per GPU, weak
-scaling); the only collective is the gather of the finished proofs to rank 0 (RCCL over xGMI).
+Default (the driver's call): ChaCha20-V3 single 64-byte blocks, one batch of --batch independent statements per GPU per step.
+A "step" is one pass of the hot path (witness -> quotient NTTs -> MSMs -> proof assembly) over that batch.  The other BASELINE
+configs are selected with --workload {chacha20,aes128,aes256,mixed} and --batch {1,64,1024,8192}; every run prints the same
+JSON line (profiles/r02_bench_*.json hold one per config).
 
-Prints ONE JSON line on rank 0 (see the harness contract): metric/value/unit..., plus
-  "roofline"      : the dominant kernel (k_msm<Fp29f,false> over the Z digit tables) priced against HBM peak, timed live with HIP events;
-  "cpu_baseline"  : the CPU oracle (oracle/, a port — not gnark) timed on the host cores on a bounded sample.
+  * chacha20 / aes128 / aes256 go through gsc_prove_raw (the binary twin of Prove: no JSON on the timed path);
+  * mixed sends a JSON array (statement i uses cipher i mod 3) through ProveBatch, all three algorithms resident on the device.
+
+Independent proofs shard across ranks (one process per GPU, weak scaling); the only collective is the gather of the finished
+proofs to rank 0 (RCCL over xGMI).  `--gpus N` without RANK in the environment makes this process a launcher: it starts N rank
+processes BEFORE anything touches torch or HIP and relays rank 0's line; under `torch.distributed.run` each rank reads
+RANK / LOCAL_RANK / WORLD_SIZE and the world size must equal --gpus.
+
+The line carries, besides the contract's keys:
+  "roofline"      : the dominant kernel (the Z-table MSM gather-accumulate of the slowest algorithm in the workload) priced against
+                    HBM peak with SURVEY.md §8(d)'s algorithmic bytes, timed live with HIP events on the kernel's own stream;
+  "msm_stage"     : the whole MSM stage in GB/s on §8(d)'s MSM bytes per proof;
+  "cpu_baseline"  : the CPU oracle (oracle/, a port — not gnark) timed on the host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,8 +33,12 @@ sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
-BYTES_PER_PROOF = 28_281_728                # algorithmic bytes of the whole path per ChaCha proof
 MSM_Z_BYTES_PER_BASE = 64 + 32              # affine G1 base + 32-byte scalar
+ALGOS = {"chacha20": (0, "chacha20", 32), "aes128": (1, "aes-128-ctr", 16), "aes256": (2, "aes-256-ctr", 32)}
+# algorithmic bytes per proof — whole path, and the MSM stage alone (AES: the survey's upper bounds)
+BYTES_PER_PROOF = {"chacha20": 28_281_728, "aes128": 115_002_752, "aes256": 129_366_656}
+MSM_BYTES_PER_PROOF = {"chacha20": 10_589_440, "aes128": 46_750_944, "aes256": 57_991_904}
+SETUP_SEEDS = {"aes128": bytes([1] * 32), "aes256": bytes([2] * 32)}      # the reference ships no pk.aes*: keys come from the product's own Setup
 
 
 def golden(name):
@@ -31,15 +47,18 @@ def golden(name):
     return lzma.open(p + ".xz").read() if os.path.exists(p + ".xz") else open(p, "rb").read()
 
 
-def pmc_traffic(batch, engine_desc):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if they were taken
-    on this configuration; None otherwise (PMC counters cannot be collected from inside the timed run)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_msm_z_pmc.json")))
-        if d["config"]["batch"] == batch and ("window_z=%d " % d["config"]["window_z"]) in engine_desc:
-            return d["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+def pmc_traffic(kernel_tag, batch, engine_desc):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if they were taken on this
+    configuration; None otherwise (PMC counters cannot be collected from inside the timed run)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_msm_z_pmc*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            c = d["config"]
+            if c.get("kernel", "") == kernel_tag and c["batch"] == batch and ("window_z=%d " % c["window_z"]) in engine_desc:
+                return d["hbm_bytes_per_launch"]
+        except Exception:
+            pass
     return None
 
 
@@ -50,6 +69,30 @@ def synthetic_records(n, seed):
     return rng.integers(0, 256, size=(n, 112), dtype=np.uint8).tobytes()
 
 
+def provable(rec, name):
+    """AES-V2 asserts counter + 4 <= 2^32 - 1 inside the circuit (circuits/aesV2/aes128.go:41-53): keep synthetic counters provable."""
+    if name == "chacha20":
+        return rec
+    b = bytearray(rec)
+    for i in range(len(b) // 112):
+        b[112 * i + 47] &= 0x7F
+    return bytes(b)
+
+
+def mixed_json(n, seed):
+    """JSON array for ProveBatch: statement i uses cipher i mod 3."""
+    import base64
+    recs = provable(synthetic_records(n, seed), "aes")
+    names = ("chacha20", "aes128", "aes256")
+    out = []
+    for i in range(n):
+        r = recs[112 * i:112 * (i + 1)]
+        _, cipher, kl = ALGOS[names[i % 3]]
+        out.append({"cipher": cipher, "key": base64.b64encode(r[:kl]).decode(), "nonce": base64.b64encode(r[32:44]).decode(),
+                    "counter": int.from_bytes(r[44:48], "little"), "input": base64.b64encode(r[48:112]).decode()})
+    return json.dumps(out).encode()
+
+
 def shard_bounds(total, world, rank):
     """Contiguous block partition of `total` units over `world` ranks (used by --total-proofs strong-scaling runs and tests)."""
     base, rem = divmod(total, world)
@@ -58,7 +101,7 @@ def shard_bounds(total, world, rank):
 
 
 def gather_proofs(dist, local: "torch.Tensor", rank, world, use_dist=None):
-    """The path's only exchange: every rank's finished proofs (164 B each) to rank 0."""
+    """The path's only exchange: every rank's finished proofs (164 / 196 B each) to rank 0."""
     import torch
     if not (world > 1 if use_dist is None else use_dist):
         return [local]
@@ -67,30 +110,93 @@ def gather_proofs(dist, local: "torch.Tensor", rank, world, use_dist=None):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` run directly (as the driver does) starts the N ranks itself
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def launch_ranks(n):
+    """Start n fresh rank processes of this script and relay rank 0's JSON line.  Nothing in this (parent) process has imported
+    torch or touched HIP: a process that initialised the GPU must never fork/exec workers."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # wait for all ranks; if one fails the others would wait for it in a collective forever, so they are stopped (exact PIDs)
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill(); rcs.append(p.wait())
+    out0 = procs[0].stdout.read()           # rank 0 writes exactly one line, at the very end
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if failed or bad or not out0.strip():
+        raise SystemExit("bench.py: rank(s) failed: %s" % (bad or "no output from rank 0"))
+    sys.stdout.write(out0.decode()); sys.stdout.flush()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle is the checker / baseline, never the product path)
 def _cpu_worker(args):
-    n, seed = args
+    name, n, seed = args
     os.environ["OMP_NUM_THREADS"] = "1"
     from oracle import oracle as O
-    cs = O.R1CS(golden("r1cs.chacha20")); pk = O.ProvingKey(golden("pk.chacha20"))
-    recs = synthetic_records(n, seed)
+    algo, cipher, kl = ALGOS[name]
+    cs = O.R1CS(golden("r1cs." + name))
+    pk = O.ProvingKey(golden("pk.chacha20") if name == "chacha20" else O.setup(cs, SETUP_SEEDS[name])[0])
+    recs = provable(synthetic_records(n, seed), name)
     t = time.time()
     for i in range(n):
         r = recs[112 * i:112 * (i + 1)]
-        O.prove(cs, pk, "chacha20", r[:32], r[32:44], int.from_bytes(r[44:48], "little"), r[48:112], 12345 + i, 67890 + i)
+        O.prove(cs, pk, cipher, r[:kl], r[32:44], int.from_bytes(r[44:48], "little"), r[48:112], 12345 + i, 67890 + i, 424242 + i)
     return time.time() - t
 
 
-def cpu_baseline(cores, per_core=24):
-    """Oracle (CPU port of the same path) on `cores` host cores: independent single-threaded provers, one per core."""
+def cpu_baseline(workload, cores):
+    """Oracle (CPU port of the same path) on `cores` host cores: independent single-threaded provers, one per core, on a bounded
+    sample of the same workload (about 10-30 s of CPU work)."""
     import multiprocessing as mp
+    names = ["chacha20", "aes128", "aes256"] if workload == "mixed" else [workload]
+    per_core = {"chacha20": 24, "aes128": 6, "aes256": 5}
     ctx = mp.get_context("spawn")
     t = time.time()
+    jobs = [(names[i % len(names)], per_core[names[i % len(names)]] if len(names) == 1 else 4, 1000 + i) for i in range(cores)]
     with ctx.Pool(cores) as pool:
-        busy = pool.map(_cpu_worker, [(per_core, 1000 + i) for i in range(cores)])
+        busy = pool.map(_cpu_worker, jobs)
     wall = time.time() - t
-    rate = cores * per_core / max(busy)        # excludes key decoding; all workers run concurrently
+    total = sum(j[1] for j in jobs)
+    rate = total / max(busy)                   # excludes key decoding / setup; all workers run concurrently
     return {"value": round(rate, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": "%d ChaCha20-V3 proofs (%d per core, single-threaded oracle per core, key decode excluded); wall %.1fs" % (cores * per_core, per_core, wall)}
+            "sample": "%d %s proofs (%s per core, single-threaded oracle per core, key decode excluded); wall %.1fs"
+                      % (total, workload, "/".join(str(j[1]) for j in jobs[:len(names)]), wall)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+class StubProver:
+    """CPU stand-in used ONLY by the launcher test (tests/test_bench_launcher.py, --stub-prover): exercises rank spawning, the
+    rendezvous, the barrier / gather / max-over-ranks plumbing with gloo.  It proves nothing and is never a fallback: the real
+    path raises when there is no GPU."""
+    def __init__(self, B):
+        import hashlib
+        self.h = hashlib
+        self.B = B
+
+    def step(self, recs):
+        time.sleep(0.01)
+        return b"".join(self.h.sha256(recs[112 * i:112 * (i + 1)]).digest() * 5 + bytes(4) for i in range(self.B)), None
 
 
 def main():
@@ -98,89 +204,126 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSC_BENCH_BATCH", "8192")), help="proofs per GPU per step")
+    ap.add_argument("--workload", choices=["chacha20", "aes128", "aes256", "mixed"], default="chacha20")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSC_BENCH_BATCH", "0")), help="proofs per GPU per step (default 8192 ChaCha, 1024 AES, 3072 mixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (rehearsal of the multi-GPU code path on a one-GPU box)")
+    ap.add_argument("--stub-prover", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: start one rank per GPU (or run `bench.py --gpus N` directly)" % (world, args.gpus))
+    workload = args.workload
+    B = args.batch or {"chacha20": 8192, "aes128": 1024, "aes256": 1024, "mixed": 3072}[workload]
     # stdout carries exactly ONE JSON line (rank 0).  Native libraries print there too (libprove reports errors on stdout like the
     # reference's fmt.Println, RCCL prints a banner), so file descriptor 1 is pointed at stderr for the whole run and the line is
     # written to the saved descriptor at the end.
     sys.stdout.flush()
     json_fd = os.dup(1); os.dup2(2, 1)
     os.environ["GSC_DEVICE"] = str(local_rank)
-    os.environ.setdefault("GSC_MAX_BATCH", str(args.batch))
+    names = ["chacha20", "aes128", "aes256"] if workload == "mixed" else [workload]
+    per_algo = B if workload != "mixed" else (B + 2) // 3
+    os.environ.setdefault("GSC_MAX_BATCH", str(max(64, (per_algo + 63) // 64 * 64)))
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
+    stub = args.stub_prover
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the prover has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if not stub:
+        torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
 
-    import gsc_loader
-    g = gsc_loader.load()
-    # Z digit tables: 13-bit digits (172 GB) is the bench configuration; fall back to narrower digits if this device cannot
-    # hold them (InitAlgorithm reports the failure and leaves the algorithm uninitialised, so it can simply be retried)
-    pk, r1cs = golden("pk.chacha20"), golden("r1cs.chacha20")
-    wanted = [os.environ["GSC_WINDOW_Z"]] if os.environ.get("GSC_WINDOW_Z") else ["13", "12", "11", "0"]
-    for wz in wanted:
-        os.environ["GSC_WINDOW_Z"] = wz
-        if g.init_algorithm(g.CHACHA20, pk, r1cs):
-            break
-    else:
-        raise SystemExit("InitAlgorithm failed")
-
-    B = args.batch
-    dev = torch.device("cuda", local_rank)
+    import numpy as np
+    g = None
+    if not stub:
+        import gsc_loader
+        g = gsc_loader.load()
+        for name in names:
+            algo = ALGOS[name][0]
+            r1cs = golden("r1cs." + name)
+            if name == "chacha20":
+                pk = golden("pk.chacha20")
+            else:
+                pk, _vk = g.setup(r1cs, SETUP_SEEDS[name])          # the product's own Groth16 Setup (GPU); deterministic in the seed
+            if not g.init_algorithm(algo, pk, r1cs):
+                raise SystemExit("InitAlgorithm failed for " + name)
 
     # statements of every step are made before the clock starts (112 B each: "inputs resident"); output buffers are reused
-    recs_of = {i: synthetic_records(B, seed=(rank << 24) + (i & 0xFFFFFF)) for i in [0x800000 + w for w in range(args.warmup)] + list(range(args.steps))}
-    import numpy as np
+    ids = [0x800000 + w for w in range(args.warmup)] + list(range(args.steps))
+    if workload == "mixed":
+        inputs_of = {i: mixed_json(B, seed=(rank << 24) + (i & 0xFFFFFF)) for i in ids}
+    else:
+        inputs_of = {i: provable(synthetic_records(B, seed=(rank << 24) + (i & 0xFFFFFF)), workload) for i in ids}
     import threading
     from concurrent.futures import ThreadPoolExecutor
     # Two callers keep the library busy, like concurrent Prove callers do (libraries/core_test.go:44-111): while one call's batch is on the
     # GPU, the other call does its host part (native cipher, CSPRNG draws, packing).  Device work of the two calls is serialised by the
     # library, so a step still means one batch through the whole path; each caller owns a set of output buffers.
-    bufs = [g.raw_buffers(B) for _ in range(2)]
+    plen = 164 if workload == "chacha20" else 196
+    bufs = [g.raw_buffers(B) if g else None for _ in range(2)]
     free = [threading.Event() for _ in range(2)]
     for e in free:
         e.set()
+    stubp = StubProver(B) if stub else None
 
     def prove(i, slot):
         free[slot].wait(); free[slot].clear()
+        if stub:
+            return stubp.step(inputs_of[i])
+        if workload == "mixed":
+            out = g.prove_batch_bytes(inputs_of[i])
+            if out.count(b'"proofJson"') != B:
+                raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, out.count(b'"proofJson"'), B))
+            return out, [(n, g.last_msm_z_kernel(ALGOS[n][0]), g.last_stage_ms(ALGOS[n][0])) for n in names]
         pb, lb, cb = bufs[slot]
-        ok = g.prove_raw_into(g.CHACHA20, recs_of[i], B, pb, lb, cb)
-        return ok, g.last_msm_z_kernel(g.CHACHA20)
+        algo = ALGOS[workload][0]
+        ok = g.prove_raw_into(algo, inputs_of[i], B, pb, lb, cb)
+        if ok != B:
+            raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, ok, B))
+        if not (np.frombuffer(lb, dtype=np.uint32) == plen).all():
+            raise SystemExit("rank %d: incomplete proofs" % rank)
+        return pb, [(workload, g.last_msm_z_kernel(algo), g.last_stage_ms(algo))]
 
-    def run(ids, kernel_ms):
+    def run(step_ids, stats):
         with ThreadPoolExecutor(2) as pool:
-            futs = [pool.submit(prove, i, k % 2) for k, i in enumerate(ids)]
+            futs = [pool.submit(prove, i, k % 2) for k, i in enumerate(step_ids)]
             for k, f in enumerate(futs):          # results are consumed in order on this thread (the only one that talks to RCCL)
-                ok, km = f.result()
-                if ok != B:
-                    raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, ok, B))
-                if not (np.frombuffer(bufs[k % 2][1], dtype=np.uint32) == 164).all():
-                    raise SystemExit("rank %d: incomplete proofs" % rank)
-                local = torch.frombuffer(bufs[k % 2][0], dtype=torch.uint8).to(dev)
+                payload, st = f.result()
+                raw = bytes(payload) if isinstance(payload, (bytes, bytearray)) else None
+                if raw is not None:               # JSON (mixed) or stub bytes: fixed-size frame for the gather
+                    frame = np.zeros(B * 416 if workload == "mixed" and not stub else len(raw), dtype=np.uint8)
+                    frame[: len(raw)] = np.frombuffer(raw, dtype=np.uint8)[: frame.size]
+                    local = torch.from_numpy(frame).to(dev)
+                else:
+                    local = torch.frombuffer(payload, dtype=torch.uint8).to(dev)
                 free[k % 2].set()
                 gather_proofs(dist, local, rank, world, use_dist)
-                kernel_ms.append(km)
+                stats.append(st)
 
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
-    run([0x800000 + w for w in range(args.warmup)], [])
+    run(ids[:args.warmup], [])
     barrier()
     t0 = time.time()
-    kernel_ms = []
-    run(list(range(args.steps)), kernel_ms)
+    stats = []
+    run(ids[args.warmup:], stats)
     barrier()
     elapsed = time.time() - t0
     if use_dist:
@@ -191,30 +334,53 @@ def main():
     if rank == 0:
         total = world * args.steps * B
         value = total / elapsed
-        ms, kb, nb = zip(*kernel_ms)
-        avg_ms = sum(ms) / len(ms)
-        alg_bytes = kb[-1] * nb[-1] * MSM_Z_BYTES_PER_BASE
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        metric = {"chacha20": "Groth16 proofs/sec (ChaCha20-V3 1-block)", "aes128": "Groth16 proofs/sec (AES-128-V2 64-byte input)",
+                  "aes256": "Groth16 proofs/sec (AES-256-V2 64-byte input)", "mixed": "Groth16 proofs/sec (mixed ChaCha20-V3 / AES-128-V2 / AES-256-V2 batch)"}[workload]
+        desc = {"chacha20": "ChaCha20-V3 single 64-byte block, reference pk.chacha20/r1cs.chacha20",
+                "aes128": "AES-128-V2 (lookup-table circuit), 64-byte input, reference r1cs.aes128, proving key from the product's Setup (the reference ships none)",
+                "aes256": "AES-256-V2 (lookup-table circuit), 64-byte input, reference r1cs.aes256, proving key from the product's Setup (the reference ships none)",
+                "mixed": "mixed batch through ProveBatch (JSON in/out): statement i uses cipher i mod 3 of chacha20 / aes-128-ctr / aes-256-ctr, all three algorithms resident"}[workload]
         line = {
-            "metric": "Groth16 proofs/sec (ChaCha20-V3 1-block)", "value": round(value, 2), "unit": "proofs/s",
+            "metric": metric, "value": round(value, 2), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fr/Fp, 254-bit modular integers)",
             "data": "synthetic",
-            "config": {"workload": "ChaCha20-V3 single 64-byte block, 1xMI355X per rank: batch of %d independent proofs per GPU per step, "
-                                   "reference pk.chacha20/r1cs.chacha20, CSPRNG (r,s)" % B,
-                       "batch_per_gpu": B, "parallelism": "proofs sharded over %d GPU(s), gather to rank 0" % world, "engine": g.describe(g.CHACHA20)},
-            "roofline": {"kernel": "k_msm<Fp29f,false> (Z-table gather-accumulate)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(kb[-1], g.describe(g.CHACHA20)),
-                         "launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
-                         "whole_path_frac": round(value / world * BYTES_PER_PROOF / 1e9 / HBM_PEAK_GBS, 6)},
-            "stage_ms_last_step": g.last_stage_ms(g.CHACHA20),
+            "config": {"workload": "%s; 1xMI355X per rank: batch of %d independent proofs per GPU per step, CSPRNG (r,s)" % (desc, B),
+                       "batch_per_gpu": B, "parallelism": "proofs sharded over %d GPU(s), gather to rank 0" % world,
+                       "engine": {n: g.describe(ALGOS[n][0]) for n in names} if g else "stub"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
-            try:
-                line["cpu_baseline"] = cpu_baseline(cores)
-            except Exception as e:      # the baseline is reported, never required for the GPU number
-                line["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
+        if not stub:
+            # dominant kernel = the Z-table MSM of the algorithm whose launch is longest; averaged over the timed steps
+            per = {}
+            for st in stats:
+                for n, (ms, kb, nb), stage in st:
+                    per.setdefault(n, []).append((ms, kb, nb, stage))
+            roofs = {}
+            for n, rows in per.items():
+                avg_ms = sum(r[0] for r in rows) / len(rows); kb, nb = rows[-1][1], rows[-1][2]
+                alg_bytes = kb * nb * MSM_Z_BYTES_PER_BASE
+                achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+                msm_ms = sum(r[3]["msm"] for r in rows) / len(rows)
+                roofs[n] = {"kernel": "k_msm_win<Fp29f> (Z-table gather-accumulate, %s)" % n, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(n, kb, g.describe(ALGOS[n][0])),
+                            "launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg_bytes, "proofs_per_launch": kb,
+                            "msm_stage": {"ms": round(msm_ms, 3), "bytes_per_proof": MSM_BYTES_PER_PROOF[n], "GB/s": round(kb * MSM_BYTES_PER_PROOF[n] / (msm_ms * 1e-3) / 1e9, 2),
+                                          "frac_of_hbm_peak": round(kb * MSM_BYTES_PER_PROOF[n] / (msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+                            "stage_ms_last_step": rows[-1][3]}
+            dom = max(roofs, key=lambda n: roofs[n]["launch_ms"])
+            line["roofline"] = dict(roofs[dom])
+            bpp = BYTES_PER_PROOF[workload] if workload != "mixed" else sum(BYTES_PER_PROOF.values()) / 3.0
+            line["roofline"]["whole_path_frac"] = round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 6)
+            line["msm_stage"] = line["roofline"].pop("msm_stage")
+            line["stage_ms_last_step"] = line["roofline"].pop("stage_ms_last_step")
+            if len(roofs) > 1:
+                line["roofline_per_algorithm"] = roofs
+            if world == 1 and not args.no_cpu_baseline:
+                cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
+                try:
+                    line["cpu_baseline"] = cpu_baseline(workload, cores)
+                except Exception as e:      # the baseline is reported, never required for the GPU number
+                    line["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:

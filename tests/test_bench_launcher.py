@@ -1,0 +1,43 @@
+"""bench.py's rank launcher on CPU: `bench.py --gpus 2` run directly (the way the driver runs it) must start two rank processes
+before anything touches torch/HIP, rendezvous on 127.0.0.1, gather to rank 0 and report n_gpus = 2.  The prover is replaced by
+bench.py's --stub-prover (gloo backend, no GPU): what is under test is the launch path the round-1 bench did not have."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_them():
+    out = subprocess.check_output([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--stub-prover"],
+                                  env=_env(), timeout=300, stderr=subprocess.DEVNULL).decode()
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1                                  # exactly one JSON line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["batch_per_gpu"] == 64 and line["unit"] == "proofs/s"
+    assert abs(line["value"] - 2 * 3 * 64 / (line["ms_per_step"] * 3 / 1e3)) / line["value"] < 0.01     # whole-job aggregate over both ranks
+
+
+def test_world_size_must_match_gpus():
+    env = dict(_env(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--stub-prover", "--steps", "1", "--warmup", "0", "--batch", "64"], env=env, capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"WORLD_SIZE=1 but --gpus 2" in p.stderr
+
+
+def test_failing_rank_fails_the_launcher():
+    # without the stub there is no GPU here: every rank exits non-zero and the launcher must say so instead of printing a line
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64"], env=_env(), capture_output=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        return
+    assert p.returncode != 0 and not p.stdout.strip()
