@@ -58,6 +58,9 @@ struct MsmSet {                     // one fixed-base MSM: tables + scalar row m
     size_t nbit = 0; DevBuf<AffT> sub; DevBuf<uint8_t> group_ok;
     // bases [0, nwide) additionally have a table with wider digits
     size_t nwide = 0; DevBuf<AffT> table2; int c2 = 0, nwin2 = 0;
+    // win: ONE table per base (table[k][d-1] = d * P_k) and one accumulator per window (k_msm_win.hip); otherwise a table per
+    // (base, window) and a single accumulator (k_msm.hip)
+    bool win = false;
 };
 
 }  // namespace
@@ -74,10 +77,11 @@ EngineConfig config_from_env() {
     c.window_w = env_int("GSC_WINDOW_W", 0);
     c.window_wide = env_int("GSC_WINDOW_WIDE", 0);
     c.z_table_gb = env_int("GSC_Z_TABLE_GB", 48);
+    c.msm_placement = env_int("GSC_MSM_PLACEMENT", 0);
     c.w_table_gb = env_int("GSC_W_TABLE_GB", 24);
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
-    if ((c.window_z && (c.window_z < 2 || c.window_z > 16)) || (c.window_w && (c.window_w < 2 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [2,16]");
+    if ((c.window_z && (c.window_z < 4 || c.window_z > 16)) || (c.window_w && (c.window_w < 2 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [2,16]");
     return c;
 }
 
@@ -112,6 +116,7 @@ class AlgorithmImpl {
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
+        DevBuf<uint4> d_digits; DevBuf<G1Xyzz> d_sj1; DevBuf<G2Xyzz> d_sj2;      // windowed sets: signed digits [window][octet][proof], per-window sums [window][proof]
         ~Lane() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;
@@ -248,7 +253,7 @@ class AlgorithmImpl {
     }
 
     template <class AffT, class Decomp, class Build>
-    void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build, size_t bases_per_slice = 16, bool wire_scalars = true) {
+    void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build, size_t bases_per_slice = 16, bool wire_scalars = true, bool win = false) {
         const size_t n = raw.size() / point_bytes;
         if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
         {   // order: [predicted full-width][predicted bits, in eights][the rest] (stable inside each part); the point at infinity is "rest"
@@ -282,15 +287,15 @@ class AlgorithmImpl {
             if (st[i] == 1) throw std::runtime_error(std::string("pk: invalid point in ") + what);
             if (st[i] == 2) rows[i] = (uint32_t)(n_wires + 3);          // point at infinity: never selected
         }
-        set.nbases = n; set.c = c; set.nwin = (254 + c - 1) / c;
+        set.nbases = n; set.c = c; set.win = win; set.nwin = win ? msm_windows(c) : (254 + c - 1) / c;
         // Slices of few bases: the wire scalars are a mix of 0/1 and full-width values clustered by wire index, so a long slice
         // full of wide scalars would be one wave's serial work for milliseconds while the rest of the chip idles (AES-V2).
         set.nslices = (n + bases_per_slice - 1) / bases_per_slice; if (!set.nslices) set.nslices = 1;
-        const size_t D = (size_t)1 << (c - 1);
-        set.table.alloc(n * set.nwin * D ? n * set.nwin * D : 1);
+        const size_t D = (size_t)1 << (c - 1), copies = win ? 1 : (size_t)set.nwin;
+        set.table.alloc(n * copies * D ? n * copies * D : 1);
         table_bytes += set.table.bytes();
         set.rows.alloc(n ? n : 1); if (n) set.rows.upload(rows.data(), n, stream);
-        build(bases.p, n, c, set.nwin, set.table.p);
+        if (win) build_base_table(bases.p, n, c, set.table.p); else build(bases.p, n, c, set.nwin, set.table.p);
         if (set.nbit) {
             const size_t ng = set.nbit / 8;
             set.sub.alloc(ng * MSM_GROUP_ENTRIES); set.group_ok.alloc(ng);
@@ -306,6 +311,19 @@ class AlgorithmImpl {
         HIP_CHECK(hipGetLastError());      // table-build launches
         HIP_CHECK(hipStreamSynchronize(stream));
     }
+    // per-base tables: threads = (base, segment of up to 256 multiples); launches of at most ~4 GiB of projective scratch
+    template <class AffT, class XyzzT, class Launch>
+    void build_base_table_impl(const AffT* b, size_t n, int c, AffT* t, Launch launch) {
+        const size_t D = (size_t)1 << (c - 1); const uint32_t seg = D < 256 ? (uint32_t)D : 256u;
+        const size_t threads = n * (D / seg);
+        size_t chunk = ((size_t)4 << 30) / (seg * sizeof(XyzzT)); if (chunk > threads) chunk = threads; if (!chunk) chunk = 1;
+        DevBuf<XyzzT> scratch(chunk * seg);
+        for (size_t t0 = 0; t0 < threads; t0 += chunk) launch(b, t0, threads - t0 < chunk ? threads - t0 : chunk, c, seg, t, scratch.p, stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    void build_base_table(const G1Aff* b, size_t n, int c, G1Aff* t) { build_base_table_impl<G1Aff, G1Xyzz>(b, n, c, t, launch_build_base_table_g1); }
+    void build_base_table(const G2Aff* b, size_t n, int c, G2Aff* t) { build_base_table_impl<G2Aff, G2Xyzz>(b, n, c, t, launch_build_base_table_g2); }
     // group tables are built in chunks so that the projective scratch stays below ~2 GiB
     void build_subset(const G1Aff* b, size_t ng, G1Aff* t, uint8_t* ok) {
         size_t chunk = ((size_t)2 << 30) / (MSM_GROUP_ENTRIES * sizeof(G1Xyzz)); if (chunk > ng) chunk = ng;
@@ -356,7 +374,8 @@ class AlgorithmImpl {
         // Digit widths: explicit (GSC_WINDOW_Z / GSC_WINDOW_W) or the largest that keeps the tables inside the per-algorithm
         // HBM budget (defaults leave room for all three algorithms of the reference on one 288 GB device).
         auto table_bytes_for = [](size_t nbases, int c, size_t entry) { return (double)nbases * ((254 + c - 1) / c) * (double)((size_t)1 << (c - 1)) * (double)entry; };
-        if (!cfg.window_z) { cfg.window_z = 4; for (int c = 13; c >= 4; c--) if (table_bytes_for(rowsZ.size(), c, 64) <= cfg.z_table_gb * 1e9) { cfg.window_z = c; break; } }
+        // Z: one table per base, 2^(c-1) entries of 64 B: c = 16 is 69 GB for ChaCha20-V3 (2^15 - 1 bases), c = 14 is 69 GB for AES-V2 (2^17 - 1)
+        if (!cfg.window_z) { cfg.window_z = 4; for (int c = 16; c >= 4; c--) if ((double)rowsZ.size() * (double)((size_t)1 << (c - 1)) * 64.0 <= cfg.z_table_gb * 1e9) { cfg.window_z = c; break; } }
         if (!cfg.window_w) {
             const size_t g1n = rowsA.size() + rowsB.size() + rowsK.size() + 2 * cs.commit_private.size(), g2n = rowsB2.size();
             cfg.window_w = 3; for (int c = 8; c >= 3; c--) if (table_bytes_for(g1n, c, 64) + table_bytes_for(g2n, c, 128) <= cfg.w_table_gb * 1e9) { cfg.window_w = c; break; }
@@ -389,7 +408,7 @@ class AlgorithmImpl {
         build_set(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, bld1, wps);
         build_set(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, bld1, wps);
         build_set(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, bld1, wps);
-        build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1, 64, false);      // uniform full-width scalars
+        build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1, 64, false, true);      // uniform full-width scalars: windowed kernel
         build_set(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, bld2, wps);
         if (cs.has_commitment) {
             if (cs.n_public_committed) throw std::runtime_error("r1cs: public committed wires are not supported");
@@ -406,12 +425,20 @@ class AlgorithmImpl {
         ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
         // partial-sum buffers: the largest slices x batch product over every batch size this context can be asked for
-        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0;
+        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj1 = 0, sj2 = 0;
+        auto need = [&](auto& m, size_t b, size_t& pa, size_t& pb, size_t& sj) {
+            if (!m.nbases) return;
+            size_t per = 0; const size_t w = m.win ? (size_t)m.nwin : 1, ns = m.win ? win_slices(m, b, per) : slices_for(m, b), bw = b * w;
+            if (ns * bw > pa) pa = ns * bw;
+            if ((ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * bw > pb) pb = (ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * bw;
+            if (m.win) { if (bw > sj) sj = bw; const size_t d = w * ((m.nbases + 7) / 8) * b; if (d > dg) dg = d; }
+        };
         for (size_t b = 64; b <= B; b += 64) {
-            for (const MsmSet<G1Aff>* m : {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}) { if (!m->nbases) continue; const size_t ns = slices_for(*m, b); if (ns * b > p1) p1 = ns * b; if ((ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * b > p1b) p1b = (ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * b; }
-            const size_t ns = slices_for(mB2, b); if (ns * b > p2) p2 = ns * b; if ((ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * b > p2b) p2b = (ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * b;
+            for (MsmSet<G1Aff>* m : {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}) need(*m, b, p1, p1b, sj1);
+            need(mB2, b, p2, p2b, sj2);
         }
         ln.d_part1a.alloc(p1); ln.d_part1b.alloc(p1b); ln.d_part2a.alloc(p2); ln.d_part2b.alloc(p2b);
+        ln.d_digits.alloc(dg); ln.d_sj1.alloc(sj1); ln.d_sj2.alloc(sj2);
         ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
         if (has_commitment) { ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_h48.alloc(48 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B); }
     }
@@ -424,7 +451,38 @@ class AlgorithmImpl {
         if (n > most) n = most;
         return n ? n : 1;
     }
+    // Windowed sets: waves = slices x windows x groups of 64 proofs.  Slices of up to 128 bases (few partial sums to reduce, a tail of
+    // < 1 % at full batches); shorter ones when that would leave fewer than ~8k waves (small batches spread over the whole chip).
+    template <class S> static size_t win_slices(const S& set, size_t B, size_t& per) {
+        const size_t gw = (B / 64) * (size_t)set.nwin, want = (8192 + gw - 1) / gw;
+        size_t n = (set.nbases + 127) / 128; if (n < want) n = want;
+        n = (n + 7) & ~(size_t)7;
+        per = ((set.nbases + n - 1) / n + 7) & ~(size_t)7; if (!per) per = 8;
+        n = (set.nbases + per - 1) / per;
+        return n ? n : 1;
+    }
+    void run_msm_win_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed) {
+        size_t per = 0; const size_t nslices = win_slices(set, B, per), Bw = B * (size_t)set.nwin;
+        MsmRecodeArgs ra{scalars, set.rows.p, mont, set.nbases, B, set.c, set.nwin, ln.d_digits.p};
+        launch_msm_recode(ra, ln.stream);
+        MsmWinArgs a{set.table.p, set.c, set.nwin, set.nbases, ln.d_digits.p, B, nslices, per, ln.d_part1a.p, cfg.msm_placement, 0};
+        if (const char* e = getenv("GSC_MSM_EXP")) { if (getenv("GSC_ENABLE_TEST_HOOKS") && (atoi(e) & 1)) a.exp_same_entry = 1; if (atoi(e) & 2) a.placement = 1; if (atoi(e) & 4) a.placement = 0; }
+        if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
+        launch_msm_win_g1(a, ln.stream);
+        if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
+        // slices -> one sum per (window, proof): the slice reduction sees nwin * B independent columns
+        G1Xyzz* src = ln.d_part1a.p; G1Xyzz* alt = ln.d_part1b.p; size_t ns = nslices;
+        for (;;) {
+            const size_t groups = msm_reduce_groups(ns, Bw);
+            G1Xyzz* dst = groups == 1 ? ln.d_sj1.p : alt;
+            launch_msm_reduce_g1(src, ns, Bw, dst, ln.stream);
+            if (groups == 1) break;
+            G1Xyzz* t = src; src = dst; alt = t; ns = groups;
+        }
+        launch_msm_horner_g1(ln.d_sj1.p, set.nwin, set.c, B, sum, ln.stream);
+    }
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
+        if (set.win) return run_msm_win_g1(ln, set, scalars, mont, B, sum, timed);
         const size_t nslices = slices_for(set, B);
         MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part1a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p, mont ? set.nwide : 0, set.table2.p, set.c2, set.nwin2};
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));

@@ -36,6 +36,7 @@ struct EngineConfig {
     int window_wide = 0;         // digit width of the second table tier (wires predicted full-width); 0 = largest <= 13 that fits wide_table_gb
     int z_table_gb = 48, w_table_gb = 24;   // per-algorithm HBM budgets used when the widths are not given
     int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no prediction-based layout; 1 bit groups / wide-digit tier from a calibration witness; 2 every wire predicted a bit (test: exercises the fallback)
+    int msm_placement = 0;       // GSC_MSM_PLACEMENT: workgroup placement of the windowed MSM kernel (kernels.hpp MsmWinArgs::placement)
     int wide_table_gb = 16;      // GSC_WIDE_TABLE_GB: budget of the wide-digit tables for wires predicted to carry full-width scalars
 };
 EngineConfig config_from_env();

@@ -109,6 +109,47 @@ inline bool msm_reduce_by_proof(size_t nslices, size_t batch) { return (batch / 
 inline size_t msm_reduce_groups(size_t nslices, size_t batch) { const size_t f = msm_reduce_by_proof(nslices, batch) ? MSM_REDUCE_FANIN : 64; return (nslices + f - 1) / f; }
 size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
 size_t launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
+// ---- windowed MSM over one table per base (k_msm_win.hip) ----
+// table[k * D + (d - 1)] = d * base[k], d = 1 .. D = 2^(c-1), affine.  Built by threads (base, segment of `seg` entries; seg divides D);
+// one launch covers threads [t0, t0 + nthreads) of that grid and needs nthreads * seg projective scratch points.
+void launch_build_base_table_g1(const G1Aff* bases, size_t t0, size_t nthreads, int c, uint32_t seg, G1Aff* table, G1Xyzz* scratch, hipStream_t s);
+void launch_build_base_table_g2(const G2Aff* bases, size_t t0, size_t nthreads, int c, uint32_t seg, G2Aff* table, G2Xyzz* scratch, hipStream_t s);
+// Signed-digit recoding of the scalars of one MSM, once per batch: digits[(j * noct + o) * batch + p] holds the eight int16 digits
+// e_{8o..8o+7, j} in [-D, D-1] of proof p (noct = ceil(nbases / 8); bases beyond nbases get zero digits).  nwin is chosen by the
+// host so that the top window never overflows (msm_windows below).
+struct MsmRecodeArgs {
+    const fe* scalars; const uint32_t* rows;   // [row][batch]; scalar row per base (nullptr: row k)
+    int mont;                                  // 1: Montgomery residues of wire values (sign-normalised before recoding), 0: canonical integers < r
+    size_t nbases, batch; int c, nwin;
+    uint4* digits;
+};
+void launch_msm_recode(const MsmRecodeArgs& a, hipStream_t s);
+// Number of windows for c-bit signed digits of scalars below r (the top window must absorb the last carry without overflow:
+// floor((r-1) / 2^(c (nwin-1))) + 1 <= 2^(c-1) - 1).  r < 2^254, top bits 0x30644e72e131a029...
+inline int msm_windows(int c) {
+    int nwin = (254 + c - 1) / c;
+    const int top_bits = 254 - c * (nwin - 1);                 // bits of r in the top window (1 .. c)
+    // value of r's top window: r >> (254 - top_bits), with r = 0x30644e72e131a029b85045b6... * 2^(254-64) (leading 64 bits are enough for c <= 32)
+    const unsigned long long lead = 0xc19139cb84c680a6ull;      // floor(r / 2^190): the 64 leading bits of r counted from bit 253
+    const unsigned long long top = lead >> (64 - top_bits);
+    if (top + 1 > (1ull << (c - 1)) - 1) nwin++;
+    return nwin;
+}
+// partial[(slice * nwin + j) * batch + p] = sum over the bases k of the slice of sign(e_kj) * table[k][|e_kj| - 1]
+struct MsmWinArgs {
+    const void* table; int c, nwin; size_t nbases;
+    const uint4* digits; size_t batch;
+    size_t nslices, per;           // slices of `per` consecutive bases (per a multiple of 8)
+    void* partial;                 // G1Xyzz / G2Xyzz [nslices][nwin][batch]
+    int placement;                 // workgroup -> (slice, window, proofs) map: 0 one XCD per slice, 1 four XCDs per slice (speed only)
+    int exp_same_entry;            // MEASUREMENT ONLY (GSC_MSM_EXP=1 with test hooks on): every gather reads entry 0 — wrong sums, pure VALU time
+};
+void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s);
+void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s);
+// out[p] = sum_j 2^(c j) S[j * batch + p]
+void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, G1Xyzz* out, hipStream_t s);
+void launch_msm_horner_g2(const G2Xyzz* S, int nwin, int c, size_t batch, G2Xyzz* out, hipStream_t s);
+
 // Commitment helpers (AES-V2).  points: batch XYZZ sums -> out: batch x 64 B big-endian canonical X|Y
 // (gnark's uncompressed G1 encoding, the prefix of the commitment hash); flags[proof] |= bit if the point is infinity.
 void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s);

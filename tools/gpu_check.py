@@ -1,5 +1,6 @@
 """Quick end-to-end check on a GPU box: KAT parity of every pipeline stage + a small timing run."""
 import hashlib, json, lzma, os, sys, time, base64
+os.environ["GSC_ENABLE_TEST_HOOKS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gsc_loader

@@ -1,5 +1,6 @@
 """AES-V2 end to end on a GPU box: keys from the oracle's Setup (no reference AES pk ships), device proof vs oracle proof."""
 import base64, json, lzma, os, sys, time, random
+os.environ["GSC_ENABLE_TEST_HOOKS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gsc_loader
