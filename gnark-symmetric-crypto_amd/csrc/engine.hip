@@ -52,15 +52,13 @@ bool be_greater(const uint8_t* a, const uint8_t* b) { int c = memcmp(a, b, 32); 
 bool be_is_zero(const uint8_t* a) { for (int i = 0; i < 32; i++) if (a[i]) return false; return true; }
 
 template <class AffT>
-struct MsmSet {                     // one fixed-base MSM: tables + scalar row map
-    DevBuf<AffT> table; DevBuf<uint32_t> rows; size_t nbases = 0; int c = 0, nwin = 0; size_t nslices = 0;
-    // bases [0, nbit) are grouped in eights with subset-sum tables (kernels.hpp MsmArgs)
-    size_t nbit = 0; DevBuf<AffT> sub; DevBuf<uint8_t> group_ok;
-    // bases [0, nwide) additionally have a table with wider digits
-    size_t nwide = 0; DevBuf<AffT> table2; int c2 = 0, nwin2 = 0;
-    // win: ONE table per base (table[k][d-1] = d * P_k) and one accumulator per window (k_msm_win.hip); otherwise a table per
-    // (base, window) and a single accumulator (k_msm.hip)
-    bool win = false;
+struct MsmSet {                     // one fixed-base MSM of the proving key (kernels.hpp, "multi-scalar multiplication")
+    size_t nbases = 0;              // bases of the key in this set
+    // windowed part (uniform rows of 2^(c-1) multiples): every base of Z; the wide wires of a wire set when there are many
+    DevBuf<AffT> wtable; DevBuf<uint32_t> wrows; size_t nwide = 0; int c = 0, nwin = 0;
+    // flat part: [bit groups of eight][narrow wires, own row lengths][window octets of a few wide wires (cv-bit digits)]
+    DevBuf<AffT> ftable; DevBuf<uint64_t> rowoff; DevBuf<uint32_t> rowlen; DevBuf<uint32_t> frows; DevBuf<int32_t> octwin;
+    size_t nflat = 0, nbit = 0, nexpanded = 0; int cv = 0; DevBuf<AffT> sub; DevBuf<uint8_t> group_ok;
 };
 
 }  // namespace
@@ -72,16 +70,15 @@ EngineConfig config_from_env() {
     c.lanes = env_int("GSC_LANES", 1);
     c.min_split = (size_t)env_int("GSC_MIN_SPLIT", 256);
     c.bit_groups = env_int("GSC_BIT_GROUPS", 1);
-    c.wide_table_gb = env_int("GSC_WIDE_TABLE_GB", 16);
     c.window_z = env_int("GSC_WINDOW_Z", 0);
     c.window_w = env_int("GSC_WINDOW_W", 0);
-    c.window_wide = env_int("GSC_WINDOW_WIDE", 0);
     c.z_table_gb = env_int("GSC_Z_TABLE_GB", 48);
+    c.w_table_gb = env_int("GSC_W_TABLE_GB", 16);
     c.msm_placement = env_int("GSC_MSM_PLACEMENT", 0);
-    c.w_table_gb = env_int("GSC_W_TABLE_GB", 24);
+    c.row_margin_bits = env_int("GSC_ROW_MARGIN_BITS", 1);
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
-    if ((c.window_z && (c.window_z < 4 || c.window_z > 16)) || (c.window_w && (c.window_w < 2 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [2,16]");
+    if ((c.window_z && (c.window_z < 4 || c.window_z > 16)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [4,16]");
     return c;
 }
 
@@ -94,7 +91,6 @@ class AlgorithmImpl {
     hipStream_t stream = nullptr;   // init-time work; proving runs on the lanes' streams
     size_t table_bytes = 0;
     std::vector<uint8_t> row_class;    // per scalar row (wire), predicted by calibrate(): 0 = always 0 or 1, 1 = also -1, else the largest bit length seen (255 = unknown)
-    static constexpr int WIDE_BITS = 64;   // wires seen above this are given wide-digit tables
 
     // program
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
@@ -116,7 +112,9 @@ class AlgorithmImpl {
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
-        DevBuf<uint4> d_digits; DevBuf<G1Xyzz> d_sj1; DevBuf<G2Xyzz> d_sj2;      // windowed sets: signed digits [window][octet][proof], per-window sums [window][proof]
+        DevBuf<uint4> d_digits; DevBuf<G1Xyzz> d_sj1; DevBuf<G2Xyzz> d_sj2;      // signed digits [window][octet][proof], per-window sums [window][proof]
+        DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
+        DevBuf<G1Xyzz> d_flat1; DevBuf<G2Xyzz> d_flat2;                           // sum of the flat part while the windowed part of the same set runs
         ~Lane() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;
@@ -252,78 +250,107 @@ class AlgorithmImpl {
         return st;
     }
 
-    template <class AffT, class Decomp, class Build>
-    void build_set(MsmSet<AffT>& set, std::vector<uint8_t> raw, size_t point_bytes, std::vector<uint32_t> rows, int c, const char* what, Decomp decomp, Build build, size_t bases_per_slice = 16, bool wire_scalars = true, bool win = false) {
-        const size_t n = raw.size() / point_bytes;
-        if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
-        {   // order: [predicted full-width][predicted bits, in eights][the rest] (stable inside each part); the point at infinity is "rest"
-            auto cls = [&](size_t i) -> int { return !wire_scalars || rows[i] >= row_class.size() || (raw[i * point_bytes] & 0xC0) == 0x40 ? 255 : row_class[rows[i]]; };
-            const bool layout = wire_scalars && cfg.bit_groups > 0;
-            std::vector<size_t> wide, bits, rest;
-            for (size_t i = 0; i < n; i++) {
-                const int c0 = cls(i);
-                if (layout && c0 <= 1) bits.push_back(i);         // values in {-1, 0, 1}: grouped in eights
-                else if (layout && c0 != 255 && c0 > WIDE_BITS) wide.push_back(i);
-                else rest.push_back(i);
-            }
-            while (wide.size() % 8 && !wide.empty()) {         // the bit groups behind must start at a multiple of 8: top up with other bases
-                if (!rest.empty()) { wide.push_back(rest.back()); rest.pop_back(); }
-                else if (!bits.empty()) { wide.push_back(bits.back()); bits.pop_back(); }
-                else break;
-            }
-            if (wide.size() % 8) { rest.insert(rest.begin(), wide.begin(), wide.end()); wide.clear(); }
-            while (bits.size() % 8) { rest.insert(rest.begin(), bits.back()); bits.pop_back(); }
-            set.nwide = wide.size(); set.nbit = bits.size();
-            if (set.nwide || set.nbit) {
-                std::vector<size_t> order(wide); order.insert(order.end(), bits.begin(), bits.end()); order.insert(order.end(), rest.begin(), rest.end());
-                std::vector<uint8_t> raw2(raw.size()); std::vector<uint32_t> rows2(n);
-                for (size_t j = 0; j < n; j++) { memcpy(raw2.data() + j * point_bytes, raw.data() + order[j] * point_bytes, point_bytes); rows2[j] = rows[order[j]]; }
-                raw.swap(raw2); rows.swap(rows2);
-            }
-        }
-        DevBuf<AffT> bases(n ? n : 1);
-        std::vector<uint8_t> st = decomp(raw, bases.p);
-        for (size_t i = 0; i < n; i++) {
-            if (st[i] == 1) throw std::runtime_error(std::string("pk: invalid point in ") + what);
-            if (st[i] == 2) rows[i] = (uint32_t)(n_wires + 3);          // point at infinity: never selected
-        }
-        set.nbases = n; set.c = c; set.win = win; set.nwin = win ? msm_windows(c) : (254 + c - 1) / c;
-        // Slices of few bases: the wire scalars are a mix of 0/1 and full-width values clustered by wire index, so a long slice
-        // full of wide scalars would be one wave's serial work for milliseconds while the rest of the chip idles (AES-V2).
-        set.nslices = (n + bases_per_slice - 1) / bases_per_slice; if (!set.nslices) set.nslices = 1;
-        const size_t D = (size_t)1 << (c - 1), copies = win ? 1 : (size_t)set.nwin;
-        set.table.alloc(n * copies * D ? n * copies * D : 1);
-        table_bytes += set.table.bytes();
-        set.rows.alloc(n ? n : 1); if (n) set.rows.upload(rows.data(), n, stream);
-        if (win) build_base_table(bases.p, n, c, set.table.p); else build(bases.p, n, c, set.nwin, set.table.p);
-        if (set.nbit) {
-            const size_t ng = set.nbit / 8;
-            set.sub.alloc(ng * MSM_GROUP_ENTRIES); set.group_ok.alloc(ng);
-            table_bytes += set.sub.bytes();
-            build_subset(bases.p + set.nwide, ng, set.sub.p, set.group_ok.p);
-        }
-        if (set.nwide) {
-            set.c2 = cfg.window_wide > c ? cfg.window_wide : c; set.nwin2 = (254 + set.c2 - 1) / set.c2;
-            set.table2.alloc(set.nwide * set.nwin2 * ((size_t)1 << (set.c2 - 1)));
-            table_bytes += set.table2.bytes();
-            build(bases.p, set.nwide, set.c2, set.nwin2, set.table2.p);
-        }
-        HIP_CHECK(hipGetLastError());      // table-build launches
-        HIP_CHECK(hipStreamSynchronize(stream));
-    }
-    // per-base tables: threads = (base, segment of up to 256 multiples); launches of at most ~4 GiB of projective scratch
-    template <class AffT, class XyzzT, class Launch>
-    void build_base_table_impl(const AffT* b, size_t n, int c, AffT* t, Launch launch) {
-        const size_t D = (size_t)1 << (c - 1); const uint32_t seg = D < 256 ? (uint32_t)D : 256u;
-        const size_t threads = n * (D / seg);
-        size_t chunk = ((size_t)4 << 30) / (seg * sizeof(XyzzT)); if (chunk > threads) chunk = threads; if (!chunk) chunk = 1;
-        DevBuf<XyzzT> scratch(chunk * seg);
-        for (size_t t0 = 0; t0 < threads; t0 += chunk) launch(b, t0, threads - t0 < chunk ? threads - t0 : chunk, c, seg, t, scratch.p, stream);
+    static constexpr size_t EXPAND_MAX = 64;      // up to this many wide wires of a set are laid out as window octets of its flat part
+    static constexpr int EXPAND_C = 15, NARROW_MAX_BITS = 14;
+
+    // rows of multiples for `n` bases (row i: len[i] entries at off[i]); work is cut into segments of at most 256 multiples
+    template <class AffT, class XyzzT>
+    void build_rows(const AffT* bases, size_t n, const std::vector<uint64_t>& off, const std::vector<uint32_t>& len, AffT* table) {
+        const uint32_t cap = 256;
+        std::vector<MsmRowSeg> segs;
+        for (size_t i = 0; i < n; i++) for (uint32_t f = 0; f < len[i]; f += cap) segs.push_back(MsmRowSeg{(uint32_t)i, f + 1, len[i] - f < cap ? len[i] - f : cap, 0u, off[i] + f});
+        if (segs.empty()) return;
+        size_t chunk = ((size_t)4 << 30) / (cap * sizeof(XyzzT)); if (chunk > segs.size()) chunk = segs.size();
+        DevBuf<XyzzT> scratch(chunk * cap); DevBuf<MsmRowSeg> d_segs(segs.size());
+        d_segs.upload(segs.data(), segs.size(), stream);
+        for (size_t t0 = 0; t0 < segs.size(); t0 += chunk) launch_build_rows(bases, d_segs.p + t0, segs.size() - t0 < chunk ? segs.size() - t0 : chunk, cap, table, scratch.p);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(stream));
     }
-    void build_base_table(const G1Aff* b, size_t n, int c, G1Aff* t) { build_base_table_impl<G1Aff, G1Xyzz>(b, n, c, t, launch_build_base_table_g1); }
-    void build_base_table(const G2Aff* b, size_t n, int c, G2Aff* t) { build_base_table_impl<G2Aff, G2Xyzz>(b, n, c, t, launch_build_base_table_g2); }
+    void launch_build_rows(const G1Aff* b, const MsmRowSeg* sg, size_t n, uint32_t cap, G1Aff* t, G1Xyzz* sc) { launch_build_rows_g1(b, sg, n, cap, t, sc, stream); }
+    void launch_build_rows(const G2Aff* b, const MsmRowSeg* sg, size_t n, uint32_t cap, G2Aff* t, G2Xyzz* sc) { launch_build_rows_g2(b, sg, n, cap, t, sc, stream); }
+    void launch_shift(const G1Aff* in, const uint32_t* src, const uint32_t* sh, size_t n, G1Aff* out) { launch_shift_bases_g1(in, src, sh, n, out, stream); }
+    void launch_shift(const G2Aff* in, const uint32_t* src, const uint32_t* sh, size_t n, G2Aff* out) { launch_shift_bases_g2(in, src, sh, n, out, stream); }
+
+    // Lays out one MSM set and builds its tables.  uniform = true (Z): every base gets a full row, windowed kernel.  Otherwise the
+    // bases are sorted by what calibrate() saw on their wires: values in {-1, 0, 1} -> bit groups of eight; values of up to
+    // NARROW_MAX_BITS bits (with the margin) -> flat rows of that length; the rest (r, s, the lookup argument's products and inverses)
+    // are wide: a few of them become window octets of the flat part, many get the windowed kernel and a Horner pass.
+    template <class AffT, class XyzzT, class Decomp>
+    void build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw, size_t point_bytes, const std::vector<uint32_t>& rows, int c, const char* what, Decomp decomp, bool uniform) {
+        const size_t n = raw.size() / point_bytes;
+        if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
+        set.nbases = n; set.c = c; set.nwin = msm_windows(c);
+        DevBuf<AffT> bases(n ? n : 1);
+        const std::vector<uint8_t> st = decomp(raw, bases.p);
+        for (size_t i = 0; i < n; i++) if (st[i] == 1) throw std::runtime_error(std::string("pk: invalid point in ") + what);
+        const size_t D = (size_t)1 << (c - 1);
+        const uint32_t ROW_ZERO = (uint32_t)(n_wires + 3);
+        std::vector<uint32_t> bits, narrow, wide;            // indices into the key's order; the point at infinity contributes nothing: dropped
+        std::vector<uint32_t> narrow_len;
+        for (size_t i = 0; i < n; i++) {
+            if (st[i] == 2) continue;
+            const int k = uniform || rows[i] >= row_class.size() ? 255 : row_class[rows[i]];
+            if (uniform || cfg.bit_groups <= 0 || k == 255 || k + cfg.row_margin_bits > NARROW_MAX_BITS) wide.push_back((uint32_t)i);
+            else if (k <= 1) bits.push_back((uint32_t)i);
+            else { narrow.push_back((uint32_t)i); const int lb = k + cfg.row_margin_bits; narrow_len.push_back(1u << (lb < 0 ? 0 : lb)); }
+        }
+        if (!uniform) {
+            while (bits.size() % 8) { narrow.insert(narrow.begin(), bits.back()); narrow_len.insert(narrow_len.begin(), 2u); bits.pop_back(); }
+            // flat part: [bits][narrow][padding to an octet][window octets of the expanded wide wires]
+            std::vector<uint32_t> src(bits), shift, frows, len; std::vector<int32_t> octwin;
+            src.insert(src.end(), narrow.begin(), narrow.end());
+            for (uint32_t i : src) frows.push_back(rows[i]);
+            len.assign(bits.size(), 1u); len.insert(len.end(), narrow_len.begin(), narrow_len.end());
+            while (src.size() % 8) { src.push_back(src.empty() ? 0u : src[0]); frows.push_back(ROW_ZERO); len.push_back(1u); }
+            shift.assign(src.size(), 0u); octwin.assign(src.size() / 8, -1);
+            const bool expand = !wide.empty() && wide.size() <= EXPAND_MAX && n > 0;
+            if (expand) {
+                set.cv = EXPAND_C; const int nwv = msm_windows(set.cv), octs = (nwv + 7) / 8;
+                for (uint32_t w : wide) for (int q = 0; q < 8 * octs; q++) {
+                    src.push_back(w); frows.push_back(rows[w]); shift.push_back(q < nwv ? (uint32_t)(set.cv * q) : 0u); len.push_back(q < nwv ? 1u << (set.cv - 1) : 1u);
+                    if (q % 8 == 0) octwin.push_back(q);
+                }
+                set.nexpanded = wide.size(); wide.clear();
+            }
+            set.nflat = src.size(); set.nbit = bits.size();
+            if (set.nflat) {
+                DevBuf<AffT> fb(set.nflat); DevBuf<uint32_t> d_src(set.nflat), d_shift(set.nflat);
+                d_src.upload(src.data(), src.size(), stream); d_shift.upload(shift.data(), shift.size(), stream);
+                launch_shift(bases.p, d_src.p, d_shift.p, set.nflat, fb.p);
+                std::vector<uint64_t> off(set.nflat); size_t entries = 0;
+                for (size_t i = 0; i < set.nflat; i++) { off[i] = entries; entries += len[i]; }
+                set.ftable.alloc(entries); table_bytes += set.ftable.bytes();
+                set.rowoff.alloc(set.nflat); set.rowlen.alloc(set.nflat); set.frows.alloc(set.nflat); set.octwin.alloc(octwin.size());
+                set.rowoff.upload(off.data(), set.nflat, stream); set.rowlen.upload(len.data(), set.nflat, stream);
+                set.frows.upload(frows.data(), set.nflat, stream); set.octwin.upload(octwin.data(), octwin.size(), stream);
+                build_rows<AffT, XyzzT>(fb.p, set.nflat, off, len, set.ftable.p);
+                if (set.nbit) {
+                    const size_t ng = set.nbit / 8;
+                    set.sub.alloc(ng * MSM_GROUP_ENTRIES); set.group_ok.alloc(ng);
+                    table_bytes += set.sub.bytes();
+                    build_subset(fb.p, ng, set.sub.p, set.group_ok.p);
+                }
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipStreamSynchronize(stream));      // fb, d_src, d_shift go out of scope
+            }
+        }
+        set.nwide = wide.size();
+        if (set.nwide) {      // windowed part: uniform rows
+            DevBuf<AffT> wb(set.nwide); DevBuf<uint32_t> d_src(set.nwide), d_shift(set.nwide);
+            std::vector<uint32_t> zero(set.nwide, 0u), wrows(set.nwide);
+            for (size_t i = 0; i < set.nwide; i++) wrows[i] = rows[wide[i]];
+            d_src.upload(wide.data(), set.nwide, stream); d_shift.upload(zero.data(), set.nwide, stream);
+            launch_shift(bases.p, d_src.p, d_shift.p, set.nwide, wb.p);
+            set.wrows.alloc(set.nwide); set.wrows.upload(wrows.data(), set.nwide, stream);
+            set.wtable.alloc(set.nwide * D); table_bytes += set.wtable.bytes();
+            std::vector<uint64_t> off(set.nwide); std::vector<uint32_t> len(set.nwide, (uint32_t)D);
+            for (size_t i = 0; i < set.nwide; i++) off[i] = i * D;
+            build_rows<AffT, XyzzT>(wb.p, set.nwide, off, len, set.wtable.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+    }
     // group tables are built in chunks so that the projective scratch stays below ~2 GiB
     void build_subset(const G1Aff* b, size_t ng, G1Aff* t, uint8_t* ok) {
         size_t chunk = ((size_t)2 << 30) / (MSM_GROUP_ENTRIES * sizeof(G1Xyzz)); if (chunk > ng) chunk = ng;
@@ -371,50 +398,32 @@ class AlgorithmImpl {
         rowsB.push_back(ROW_ONE); rowsB.push_back(ROW_S); rowsB2.push_back(ROW_ONE); rowsB2.push_back(ROW_S);
         rowsK.push_back(ROW_NRS);
         std::vector<uint32_t> rowsZ(domain_n - 1); for (size_t i = 0; i < rowsZ.size(); i++) rowsZ[i] = (uint32_t)i;
-        // Digit widths: explicit (GSC_WINDOW_Z / GSC_WINDOW_W) or the largest that keeps the tables inside the per-algorithm
-        // HBM budget (defaults leave room for all three algorithms of the reference on one 288 GB device).
-        auto table_bytes_for = [](size_t nbases, int c, size_t entry) { return (double)nbases * ((254 + c - 1) / c) * (double)((size_t)1 << (c - 1)) * (double)entry; };
-        // Z: one table per base, 2^(c-1) entries of 64 B: c = 16 is 69 GB for ChaCha20-V3 (2^15 - 1 bases), c = 14 is 69 GB for AES-V2 (2^17 - 1)
+        // Digit widths: explicit (GSC_WINDOW_Z / GSC_WINDOW_W) or the largest that keeps the tables inside the per-algorithm HBM
+        // budget (the defaults leave room for all three algorithms of the reference on one 288 GB device: 3 x (48 + 16) GB).
+        // Z: uniform rows of 2^(c-1) entries of 64 B: c = 16 is 69 GB for ChaCha20-V3 (2^15 - 1 bases), c = 14 is 69 GB for AES-V2 (2^17 - 1)
         if (!cfg.window_z) { cfg.window_z = 4; for (int c = 16; c >= 4; c--) if ((double)rowsZ.size() * (double)((size_t)1 << (c - 1)) * 64.0 <= cfg.z_table_gb * 1e9) { cfg.window_z = c; break; } }
-        if (!cfg.window_w) {
-            const size_t g1n = rowsA.size() + rowsB.size() + rowsK.size() + 2 * cs.commit_private.size(), g2n = rowsB2.size();
-            cfg.window_w = 3; for (int c = 8; c >= 3; c--) if (table_bytes_for(g1n, c, 64) + table_bytes_for(g2n, c, 128) <= cfg.w_table_gb * 1e9) { cfg.window_w = c; break; }
-        }
-        if (!cfg.window_wide) {      // wide-digit tier: the widest digits whose tables for the predicted full-width wires fit the budget
-            auto nwide = [&](const std::vector<uint32_t>& rows) { size_t k = 0; for (uint32_t r : rows) if (r < row_class.size() && row_class[r] != 255 && row_class[r] > WIDE_BITS) k++; return k + 8; };
-            const size_t g1w = nwide(rowsA) + nwide(rowsB) + nwide(rowsK) + 2 * nwide(cs.commit_private), g2w = nwide(rowsB2);
-            cfg.window_wide = cfg.window_w; for (int c = 13; c > cfg.window_w; c--) if (table_bytes_for(g1w, c, 64) + table_bytes_for(g2w, c, 128) <= cfg.wide_table_gb * 1e9) { cfg.window_wide = c; break; }
+        if (!cfg.window_w) {      // wire sets: only the wide wires that get the windowed kernel (more than EXPAND_MAX per set) pay for c
+            auto wide_of = [&](const std::vector<uint32_t>& rows) {
+                size_t k = 0;
+                for (uint32_t r : rows) { const int cl = r < row_class.size() ? row_class[r] : 255; if (cfg.bit_groups <= 0 || cl == 255 || cl + cfg.row_margin_bits > NARROW_MAX_BITS) k++; }
+                return k > EXPAND_MAX ? (double)k : 0.0;
+            };
+            const double g1 = wide_of(rowsA) + wide_of(rowsB) + wide_of(rowsK) + 2 * wide_of(cs.commit_private), g2 = wide_of(rowsB2);
+            cfg.window_w = 4;
+            for (int c = 16; c >= 4; c--) if ((g1 * 64.0 + g2 * 128.0) * (double)((size_t)1 << (c - 1)) <= cfg.w_table_gb * 1e9) { cfg.window_w = c; break; }
         }
         auto dec1 = [this](const std::vector<uint8_t>& raw, G1Aff* out) { return decompress_g1(raw, out); };
         auto dec2 = [this](const std::vector<uint8_t>& raw, G2Aff* out) { return decompress_g2(raw, out); };
-        // tables are built in chunks of rows so that the projective scratch stays below ~4 GiB
-        auto bld1 = [this](const G1Aff* b, size_t n, int c, int nwin, G1Aff* t) {
-            const size_t D = (size_t)1 << (c - 1), rows = n * (size_t)nwin;
-            size_t chunk = ((size_t)4 << 30) / (D * sizeof(G1Xyzz)); if (chunk > rows) chunk = rows; if (!chunk) chunk = 1;
-            DevBuf<G1Xyzz> scratch(chunk * D);
-            for (size_t r0 = 0; r0 < rows; r0 += chunk) launch_build_table_g1(b, r0, rows - r0 < chunk ? rows - r0 : chunk, c, nwin, t, scratch.p, stream);
-            HIP_CHECK(hipStreamSynchronize(stream));
-        };
-        auto bld2 = [this](const G2Aff* b, size_t n, int c, int nwin, G2Aff* t) {
-            const size_t D = (size_t)1 << (c - 1), rows = n * (size_t)nwin;
-            size_t chunk = ((size_t)4 << 30) / (D * sizeof(G2Xyzz)); if (chunk > rows) chunk = rows; if (!chunk) chunk = 1;
-            DevBuf<G2Xyzz> scratch(chunk * D);
-            for (size_t r0 = 0; r0 < rows; r0 += chunk) launch_build_table_g2(b, r0, rows - r0 < chunk ? rows - r0 : chunk, c, nwin, t, scratch.p, stream);
-            HIP_CHECK(hipStreamSynchronize(stream));
-        };
-        // wire MSMs: bit-only circuits (ChaCha) are uniform, so long slices are fine; circuits with lookups / commitments
-        // (AES-V2) carry clusters of full-width wires and want short slices (see build_set)
-        const size_t wps = cs.has_commitment ? 16 : 64;
-        build_set(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, bld1, wps);
-        build_set(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, bld1, wps);
-        build_set(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, bld1, wps);
-        build_set(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, bld1, 64, false, true);      // uniform full-width scalars: windowed kernel
-        build_set(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, bld2, wps);
+        build_set<G1Aff, G1Xyzz>(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, false);
+        build_set<G1Aff, G1Xyzz>(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, false);
+        build_set<G1Aff, G1Xyzz>(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, false);
+        build_set<G1Aff, G1Xyzz>(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, true);      // uniform full-width scalars
+        build_set<G2Aff, G2Xyzz>(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, false);
         if (cs.has_commitment) {
             if (cs.n_public_committed) throw std::runtime_error("r1cs: public committed wires are not supported");
             if (key.ped_basis.size() != cs.commit_private.size() * 32) throw std::runtime_error("pk: commitment basis size does not match the r1cs");
-            build_set(mPed, key.ped_basis, 32, cs.commit_private, cfg.window_w, "commitment basis", dec1, bld1);
-            build_set(mPedSigma, key.ped_basis_sigma, 32, cs.commit_private, cfg.window_w, "commitment basis (sigma)", dec1, bld1);
+            build_set<G1Aff, G1Xyzz>(mPed, key.ped_basis, 32, cs.commit_private, cfg.window_w, "commitment basis", dec1, false);
+            build_set<G1Aff, G1Xyzz>(mPedSigma, key.ped_basis_sigma, 32, cs.commit_private, cfg.window_w, "commitment basis (sigma)", dec1, false);
         }
     }
 
@@ -424,91 +433,81 @@ class AlgorithmImpl {
         for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
         ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
-        // partial-sum buffers: the largest slices x batch product over every batch size this context can be asked for
-        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj1 = 0, sj2 = 0;
+        // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
+        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj1 = 0, sj2 = 0, gk = 0;
         auto need = [&](auto& m, size_t b, size_t& pa, size_t& pb, size_t& sj) {
-            if (!m.nbases) return;
-            size_t per = 0; const size_t w = m.win ? (size_t)m.nwin : 1, ns = m.win ? win_slices(m, b, per) : slices_for(m, b), bw = b * w;
-            if (ns * bw > pa) pa = ns * bw;
-            if ((ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * bw > pb) pb = (ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * bw;
-            if (m.win) { if (bw > sj) sj = bw; const size_t d = w * ((m.nbases + 7) / 8) * b; if (d > dg) dg = d; }
+            auto part = [&](size_t nb, size_t ns, size_t cols) {
+                if (ns * cols > pa) pa = ns * cols;
+                if ((ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * cols > pb) pb = (ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * cols;
+            };
+            size_t per = 0;
+            if (m.nflat) { part(m.nflat, msm_slices(m.nflat, 1, 256, b, per), b); if (m.nflat / 8 * b > dg) dg = m.nflat / 8 * b; if (m.nbit / 8 * (b / 64) > gk) gk = m.nbit / 8 * (b / 64); }
+            if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, 128, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
         };
         for (size_t b = 64; b <= B; b += 64) {
             for (MsmSet<G1Aff>* m : {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}) need(*m, b, p1, p1b, sj1);
             need(mB2, b, p2, p2b, sj2);
         }
         ln.d_part1a.alloc(p1); ln.d_part1b.alloc(p1b); ln.d_part2a.alloc(p2); ln.d_part2b.alloc(p2b);
-        ln.d_digits.alloc(dg); ln.d_sj1.alloc(sj1); ln.d_sj2.alloc(sj2);
+        ln.d_digits.alloc(dg); ln.d_sj1.alloc(sj1); ln.d_sj2.alloc(sj2); ln.d_gok.alloc(gk ? gk : 1); ln.d_flat1.alloc(B); ln.d_flat2.alloc(B);
         ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
         if (has_commitment) { ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_h48.alloc(48 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B); }
     }
 
-    // Slices per launch: the key's default (64 or 16 bases per slice) for big batches; for small batches more, shorter slices
-    // so that a single proof still spreads over the whole chip (~8k waves) instead of 512 long-running waves.
-    template <class S> static size_t slices_for(const S& set, size_t B) {
-        const size_t groups = B / 64, want = (8192 + groups - 1) / groups, most = (set.nbases + 3) / 4;
-        size_t n = set.nslices > want ? set.nslices : want;
-        if (n > most) n = most;
-        return n ? n : 1;
-    }
-    // Windowed sets: waves = slices x windows x groups of 64 proofs.  Slices of up to 128 bases (few partial sums to reduce, a tail of
-    // < 1 % at full batches); shorter ones when that would leave fewer than ~8k waves (small batches spread over the whole chip).
-    template <class S> static size_t win_slices(const S& set, size_t B, size_t& per) {
-        const size_t gw = (B / 64) * (size_t)set.nwin, want = (8192 + gw - 1) / gw;
-        size_t n = (set.nbases + 127) / 128; if (n < want) n = want;
+    // Waves of an MSM launch = slices x windows x groups of 64 proofs (windows = 1 for the flat kernel).  Slices of up to `most`
+    // bases (few partial sums to reduce, a tail of < 1 % at full batches); shorter ones when that would leave fewer than ~8k waves,
+    // so that a small batch still spreads over the whole chip.
+    static size_t msm_slices(size_t nbases, size_t nwin, size_t most, size_t B, size_t& per) {
+        const size_t gw = (B / 64) * nwin, want = (8192 + gw - 1) / gw;
+        size_t n = (nbases + most - 1) / most; if (n < want) n = want;
         n = (n + 7) & ~(size_t)7;
-        per = ((set.nbases + n - 1) / n + 7) & ~(size_t)7; if (!per) per = 8;
-        n = (set.nbases + per - 1) / per;
+        per = ((nbases + n - 1) / n + 7) & ~(size_t)7; if (!per) per = 8;
+        n = (nbases + per - 1) / per;
         return n ? n : 1;
     }
-    void run_msm_win_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed) {
-        size_t per = 0; const size_t nslices = win_slices(set, B, per), Bw = B * (size_t)set.nwin;
-        MsmRecodeArgs ra{scalars, set.rows.p, mont, set.nbases, B, set.c, set.nwin, ln.d_digits.p};
-        launch_msm_recode(ra, ln.stream);
-        MsmWinArgs a{set.table.p, set.c, set.nwin, set.nbases, ln.d_digits.p, B, nslices, per, ln.d_part1a.p, cfg.msm_placement, 0};
-        if (const char* e = getenv("GSC_MSM_EXP")) { if (getenv("GSC_ENABLE_TEST_HOOKS") && (atoi(e) & 1)) a.exp_same_entry = 1; if (atoi(e) & 2) a.placement = 1; if (atoi(e) & 4) a.placement = 0; }
-        if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
-        launch_msm_win_g1(a, ln.stream);
-        if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
-        // slices -> one sum per (window, proof): the slice reduction sees nwin * B independent columns
-        G1Xyzz* src = ln.d_part1a.p; G1Xyzz* alt = ln.d_part1b.p; size_t ns = nslices;
+    template <class XyzzT, class LR>
+    void reduce_slices(Lane& ln, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, XyzzT* out, LR launch_reduce) {
+        XyzzT* src = pa; XyzzT* alt = pb; size_t ns = nslices;
         for (;;) {
-            const size_t groups = msm_reduce_groups(ns, Bw);
-            G1Xyzz* dst = groups == 1 ? ln.d_sj1.p : alt;
-            launch_msm_reduce_g1(src, ns, Bw, dst, ln.stream);
+            const size_t groups = msm_reduce_groups(ns, cols);
+            XyzzT* dst = groups == 1 ? out : alt;
+            launch_reduce(src, ns, cols, dst, ln.stream);
             if (groups == 1) break;
-            G1Xyzz* t = src; src = dst; alt = t; ns = groups;
+            XyzzT* t = src; src = dst; alt = t; ns = groups;
         }
-        launch_msm_horner_g1(ln.d_sj1.p, set.nwin, set.c, B, sum, ln.stream);
+    }
+    // scalars: the wire matrix W (Montgomery; wire sets) or h (canonical; Z)
+    template <class AffT, class XyzzT, class LF, class LW, class LR, class LH>
+    void run_msm(Lane& ln, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
+                 LF launch_flat, LW launch_win, LR launch_reduce, LH launch_horner) {
+        size_t per = 0;
+        if (set.nflat) {
+            const size_t nslices = msm_slices(set.nflat, 1, 256, B, per);
+            MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ln.d_digits.p, set.nbit, set.group_ok.p, ln.d_gok.p};
+            launch_msm_recode_flat(ra, ln.stream);
+            MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ln.d_digits.p, B, nslices, per, pa, set.nbit, set.sub.p, ln.d_gok.p, scalars, set.frows.p};
+            launch_flat(a, ln.stream);
+            reduce_slices(ln, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
+        }
+        if (set.nwide) {
+            const size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, 128, B, per), Bw = B * (size_t)set.nwin;
+            MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ln.d_digits.p};
+            launch_msm_recode(ra, ln.stream);
+            MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ln.d_digits.p, B, nslices, per, pa, cfg.msm_placement, 0};
+            if (const char* e = getenv("GSC_MSM_EXP")) { if (getenv("GSC_ENABLE_TEST_HOOKS") && (atoi(e) & 1)) a.exp_same_entry = 1; if (atoi(e) & 2) a.placement = 1; if (atoi(e) & 4) a.placement = 0; }
+            if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
+            launch_win(a, ln.stream);
+            if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
+            reduce_slices(ln, pa, pb, nslices, Bw, sj, launch_reduce);      // slices -> one sum per (window, proof)
+            launch_horner(sj, set.nwin, set.c, B, set.nflat ? flat : (XyzzT*)nullptr, sum, ln.stream);
+        }
+        if (!set.nflat && !set.nwide) HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ln.stream));      // empty set: the point at infinity
     }
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
-        if (set.win) return run_msm_win_g1(ln, set, scalars, mont, B, sum, timed);
-        const size_t nslices = slices_for(set, B);
-        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part1a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p, mont ? set.nwide : 0, set.table2.p, set.c2, set.nwin2};
-        if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
-        launch_msm_g1(a, ln.stream);
-        if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
-        G1Xyzz* src = ln.d_part1a.p; G1Xyzz* alt = ln.d_part1b.p; size_t ns = nslices;
-        for (;;) {
-            const size_t groups = msm_reduce_groups(ns, B);
-            G1Xyzz* dst = groups == 1 ? sum : alt;
-            launch_msm_reduce_g1(src, ns, B, dst, ln.stream);
-            if (groups == 1) break;
-            G1Xyzz* t = src; src = dst; alt = t; ns = groups;
-        }
+        run_msm(ln, set, scalars, mont != 0, B, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1.p, ln.d_flat1.p, sum, timed, launch_msm_flat_g1, launch_msm_win_g1, launch_msm_reduce_g1, launch_msm_horner_g1);
     }
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
-        const size_t nslices = slices_for(set, B);
-        MsmArgs a{set.table.p, set.c, set.nwin, set.nbases, set.rows.p, scalars, mont, B, nslices, ln.d_part2a.p, mont ? set.nbit : 0, set.sub.p, set.group_ok.p, mont ? set.nwide : 0, set.table2.p, set.c2, set.nwin2};
-        launch_msm_g2(a, ln.stream);
-        G2Xyzz* src = ln.d_part2a.p; G2Xyzz* alt = ln.d_part2b.p; size_t ns = nslices;
-        for (;;) {
-            const size_t groups = msm_reduce_groups(ns, B);
-            G2Xyzz* dst = groups == 1 ? sum : alt;
-            launch_msm_reduce_g2(src, ns, B, dst, ln.stream);
-            if (groups == 1) break;
-            G2Xyzz* t = src; src = dst; alt = t; ns = groups;
-        }
+        run_msm(ln, set, scalars, mont != 0, B, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, launch_msm_flat_g2, launch_msm_win_g2, launch_msm_reduce_g2, launch_msm_horner_g2);
     }
 
     void fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
@@ -656,12 +655,13 @@ Algorithm::~Algorithm() = default;
 Cipher Algorithm::cipher() const { return impl_->cipher; }
 size_t Algorithm::max_batch() const { return impl_->cap; }
 void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impl_->lanes[0]->stage_ms[i]; }
-float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impl_->lanes[0]->last_batch; if (nbases) *nbases = impl_->mZ.nbases; return impl_->lanes[0]->msm_z_kernel_ms; }
+float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impl_->lanes[0]->last_batch; if (nbases) *nbases = impl_->mZ.nwide; return impl_->lanes[0]->msm_z_kernel_ms; }
 std::string Algorithm::describe() const {
     char buf[512];
-    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu window_z=%d window_w=%d window_wide=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu",
-             impl_->n_wires, impl_->n_constraints, impl_->L, impl_->cap, impl_->lanes.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->cfg.window_wide, impl_->table_bytes / 1073741824.0,
-             impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases);
+    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu grouped A=%zu B=%zu K=%zu wide(windowed+expanded) A=%zu+%zu B=%zu+%zu K=%zu+%zu",
+             impl_->n_wires, impl_->n_constraints, impl_->L, impl_->cap, impl_->lanes.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
+             impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases, impl_->mA.nbit, impl_->mB1.nbit, impl_->mK.nbit,
+             impl_->mA.nwide, impl_->mA.nexpanded, impl_->mB1.nwide, impl_->mB1.nexpanded, impl_->mK.nwide, impl_->mK.nexpanded);
     return buf;
 }
 size_t Algorithm::domain_size() const { return impl_->domain_n; }

@@ -31,13 +31,12 @@ struct EngineConfig {
     size_t max_batch = 1024;     // proofs in flight over all lanes (rounded to a multiple of 64 per lane)
     int lanes = 1;               // concurrent HIP streams, each with its own batch buffers (GSC_LANES)
     size_t min_split = 256;      // a call with at least 2*min_split proofs is spread over the lanes (GSC_MIN_SPLIT)
-    int window_z = 0;            // digit width of the Z (quotient) tables; 0 = largest that fits z_table_gb (ChaCha: 12 -> 94 GB, 13 -> 172 GB; bench.py uses 13)
-    int window_w = 0;            // digit width of the A / B1 / B2 / K / commitment tables; 0 = largest <= 8 that fits w_table_gb
-    int window_wide = 0;         // digit width of the second table tier (wires predicted full-width); 0 = largest <= 13 that fits wide_table_gb
-    int z_table_gb = 48, w_table_gb = 24;   // per-algorithm HBM budgets used when the widths are not given
-    int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no prediction-based layout; 1 bit groups / wide-digit tier from a calibration witness; 2 every wire predicted a bit (test: exercises the fallback)
-    int msm_placement = 0;       // GSC_MSM_PLACEMENT: workgroup placement of the windowed MSM kernel (kernels.hpp MsmWinArgs::placement)
-    int wide_table_gb = 16;      // GSC_WIDE_TABLE_GB: budget of the wide-digit tables for wires predicted to carry full-width scalars
+    int window_z = 0;            // digit width of the Z (quotient) rows: 2^(c-1) multiples of each of the n-1 bases; 0 = largest <= 16 that fits z_table_gb
+    int window_w = 0;            // digit width of the A / B1 / B2 / K / commitment sets; 0 = largest <= 16 that fits w_table_gb
+    int z_table_gb = 48, w_table_gb = 16;   // per-algorithm HBM budgets used when the widths are not given (all three algorithms of the reference fit one 288 GB device)
+    int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no prediction-based layout; 1 bit groups / row lengths from a calibration witness; 2 every wire predicted a bit (test: exercises the fallbacks)
+    int row_margin_bits = 1;     // GSC_ROW_MARGIN_BITS: a wire seen with k-bit values gets a row of 2^(k + margin) multiples (capped at 2^(c-1))
+    int msm_placement = 0;       // GSC_MSM_PLACEMENT: workgroup placement of the MSM kernel (kernels.hpp MsmWinArgs::placement)
 };
 EngineConfig config_from_env();
 

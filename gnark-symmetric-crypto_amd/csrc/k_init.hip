@@ -128,45 +128,6 @@ __device__ __forceinline__ Aff9<Fp2x> base_to_fp29(const Aff<Fp2>* b) {
     return Aff9<Fp2x>{fe9x2{to_fp29(b->x.a0), to_fp29(b->x.a1)}, fe9x2{to_fp29(b->y.a0), to_fp29(b->y.a1)}};
 }
 
-// One thread per table row (base k, window j).  Forward pass: E_d = d*Bj in XYZZ, parked in `scratch`, with the running
-// product of the ZZZ_d parked in the row's own slots; one inversion per row; the backward pass turns every E_d into
-// its affine form (Montgomery batch inversion).  Rows [row0, row0 + nrows) are processed; scratch holds nrows*D points.
-// Table entries and scratch are memory images of radix-2^29 values (bn254_fp29.hpp).
-template <class F, class OldF>
-__global__ void k_build_table(const Aff<OldF>* bases, size_t row0, size_t nrows, int c, int nwin, fe* table, fe* scratch) {
-    using C = Curve9<F>;
-    using E = typename F::E;
-    constexpr int CW = F::WORDS;              // field elements per coordinate
-    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= nrows) return;
-    size_t row = row0 + t;
-    size_t k = row / nwin; int j = (int)(row % nwin);
-    const size_t D = (size_t)1 << (c - 1);
-    Xyzz9<F> P = C::from_aff(base_to_fp29(bases + k));
-    for (int q = 0; q < c * j; q++) P = C::dbl(P);
-    Aff9<F> Bj = C::to_aff(P);
-    fe* out = table + row * D * (2 * CW);
-    fe* sc = scratch + t * D * (4 * CW);
-    Xyzz9<F> Ed = C::from_aff(Bj);
-    E prefix = F::one();
-    for (size_t d = 1; d <= D; d++) {
-        if (d > 1) Ed = C::template madd<true>(Ed, Bj);
-        C::store_xyzz(sc + (d - 1) * (4 * CW), Ed);
-        F::store(out + (d - 1) * (2 * CW), prefix);                 // product of ZZZ_1 .. ZZZ_{d-1}
-        prefix = F::mul(prefix, Ed.zzz);
-    }
-    E inv = F::inv(prefix);
-    for (size_t d = D; d >= 1; d--) {
-        Ed = C::load_xyzz(sc + (d - 1) * (4 * CW));
-        E pre = F::load(out + (d - 1) * (2 * CW));
-        E izzz = F::mul(inv, pre);             // 1 / ZZZ_d
-        inv = F::mul(inv, Ed.zzz);
-        E izz = F::mul(F::sqr(Ed.zz), F::sqr(izzz));   // 1/ZZ = ZZ^2 / ZZZ^2
-        Aff9<F> a; a.x = F::mul(Ed.x, izz); a.y = F::mul(Ed.y, izzz);
-        C::store_aff(out + (d - 1) * (2 * CW), a);
-    }
-}
-
 // Signed subset-sum tables for groups of eight bases whose scalars are -1, 0 or 1 in (almost) every proof: entry v-1 of group g is
 // sum_i t_i * P_{8g+i} for the balanced-ternary value v = sum_i t_i 3^i, v = 1 .. (3^8-1)/2, affine (negative v: the negated entry).
 // One thread per group.  With k the position of the leading digit (which is +1 for v > 0), v = 3^k + s with |s| <= (3^k-1)/2, so
@@ -309,14 +270,6 @@ void launch_fr_from_be(const uint8_t* in, fe* out, size_t n, hipStream_t s) {
 }
 void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fr_inverse, dim3(blocks_for(n, 64)), dim3(64), 0, s, in, out, n);
-}
-void launch_build_table_g1(const G1Aff* bases, size_t row0, size_t nrows, int c, int nwin, G1Aff* table, G1Xyzz* scratch, hipStream_t s) {
-    if (nrows) hipLaunchKernelGGL((k_build_table<Fp29f, Fp>), dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
-                                  reinterpret_cast<const Aff<Fp>*>(bases), row0, nrows, c, nwin, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
-}
-void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c, int nwin, G2Aff* table, G2Xyzz* scratch, hipStream_t s) {
-    if (nrows) hipLaunchKernelGGL((k_build_table<Fp2x, Fp2>), dim3(blocks_for(nrows, 64)), dim3(64), 0, s,
-                                  reinterpret_cast<const Aff<Fp2>*>(bases), row0, nrows, c, nwin, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
 }
 void launch_build_subset_g1(const G1Aff* bases, size_t ngroups, G1Aff* table, G1Xyzz* scratch, uint8_t* ok, hipStream_t s) {
     if (ngroups) hipLaunchKernelGGL((k_build_subset<Fp29f, Fp>), dim3(blocks_for(ngroups, 64)), dim3(64), 0, s,

@@ -1,14 +1,7 @@
-// Fixed-base multi-scalar multiplication over HBM-resident digit tables, and proof assembly.
+// Slice reductions of the MSMs, wire classification (calibration) and proof assembly.
 //
-// Replaces the five MultiExp calls of groth16.Prove (reference libraries/prover/impl/provers.go:148,216;
-// gnark-crypto (*G1Jac).MultiExp / (*G2Jac).MultiExp — SURVEY.md §8(a) a8-a12, algebra App. D).
-//
-// Every base of a proving key is fixed for the life of the process, and an MI355X has 288 GB of HBM, so
-// InitAlgorithm precomputes T[k][j][d] = d * 2^(c j) * P_k for all signed c-bit digits d (k_init.hip).
-// An MSM is then a pure gather-accumulate: sum_k sum_j +-T[k][j][|d_kj|] — no buckets, no sorting, no
-// atomics, no inter-thread hazards.  Lanes of a wave are 64 proofs working on the same base k, so the
-// scalar loads are coalesced (2 KiB per wave) and the table gathers of a wave fall into one 2^(c-1)*64 B row.
-// Partial sums per (slice of bases, proof) are reduced with wavefront __shfl_xor butterflies.
+// The gather-accumulate kernels themselves are in k_msm_win.hip; this file holds what follows them in groth16.Prove
+// (reference libraries/prover/impl/provers.go:148,216; SURVEY.md §8(a) a9 msmReduceChunk, a12 assembly, App. D).
 #include "kernels.hpp"
 #include "bn254_fp29.hpp"
 
@@ -17,7 +10,6 @@ using namespace bn254;
 
 namespace {
 
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // |s| <= (r-1)/2 after sign normalisation; returns true when the point must be negated
 __device__ __forceinline__ bool sign_normalise(fe& s) {
@@ -36,142 +28,6 @@ __device__ __forceinline__ bool sign_normalise(fe& s) {
         for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)FrParams::mod(i) - s.l[i] - br; s.l[i] = (uint32_t)d; br = (d >> 32) & 1; }
     }
     return gt;
-}
-
-// raw memory image of one affine table entry (2 * WORDS field elements), kept packed until it is consumed
-template <class F> struct RawAff { fe w[2 * F::WORDS]; };
-template <class F> __device__ __forceinline__ RawAff<F> load_raw(const fe* p) {
-    RawAff<F> r;
-#pragma unroll
-    for (int i = 0; i < 2 * F::WORDS; i++) r.w[i] = load_fe(p + i);
-    return r;
-}
-__device__ __forceinline__ Aff9<Fp29f> unpack_aff(const RawAff<Fp29f>& r, bool negate) {
-    Aff9<Fp29f> e{Fp29::unpack(r.w[0]), Fp29::unpack(r.w[1])};
-    if (negate) e.y = Fp29::neg(e.y);                      // signed-tight: fine as a product operand
-    return e;
-}
-__device__ __forceinline__ Aff9<Fp2x> unpack_aff(const RawAff<Fp2x>& r, bool negate) {
-    Aff9<Fp2x> e{fe9x2{Fp29::unpack(r.w[0]), Fp29::unpack(r.w[1])}, fe9x2{Fp29::unpack(r.w[2]), Fp29::unpack(r.w[3])}};
-    if (negate) e.y = Fp2x::neg(e.y);
-    return e;
-}
-
-// One slice of bases for one proof (lane).  EXACT = false is the hot path (no degenerate-case tests inside madd).
-// Software pipelining: the table entry for the NEXT non-zero digit and the scalar of the NEXT base are requested before the
-// current mixed addition (~2 500 instructions) starts, so the 64-byte random HBM gathers are never on the critical path.
-//
-// Groups (bases [nwide, nwide + nbit)): every wire of these circuits is tiny after sign normalisation — ChaCha20-V3: 62 % bits,
-// 38 % values in {-1, 0, 1} — and lanes are different proofs, so a wave pays one mixed addition per base as soon as a single
-// proof has a non-zero value.  Eight such bases are taken together instead: the eight scalars become a balanced-ternary number
-// and ONE addition of the tabulated signed subset sum replaces up to eight.  The grouping is a prediction made at
-// InitAlgorithm; here every wave checks it (all 64 proofs, all eight scalars in {-1, 0, 1}) and otherwise walks the eight
-// bases through the digit tables like any other base, so results never depend on the prediction.
-template <class F, bool EXACT, bool BITS>
-__device__ __forceinline__ Xyzz9<F> accumulate_slice(const MsmArgs& a, size_t k0, size_t k1, size_t p) {
-    using C = Curve9<F>;
-    const fe* sub = reinterpret_cast<const fe*>(a.sub);
-    const size_t bit0 = BITS ? a.nwide : 0, bit1 = BITS ? a.nwide + a.nbit : 0;
-    fe minus_one;                                   // -1 in the representation of the scalars
-    {
-        fe one1 = fe{}; one1.l[0] = 1;
-        minus_one = Fr::neg(a.scalars_mont ? Fr::one() : one1);
-    }
-    Xyzz9<F> acc = C::infinity();
-    RawAff<F> pend; bool have = false, pend_neg = false;
-    auto scalar_of = [&](size_t k) { const size_t row = a.rows ? uni(a.rows[k]) : k; return load_fe(a.scalars + row * a.batch + p); };
-    size_t k = k0, single_until = 0;        // bases below single_until are walked one by one even inside the bit-group region
-    fe s_next = fe{}; bool have_next = false;
-    while (k < k1) {
-        if (BITS && k >= bit0 && k < bit1 && k >= single_until) {      // wave-uniform: k is a multiple of 8 here
-            int32_t v = 0; bool ok = true;
-#pragma unroll 1
-            for (int h = 0; h < 8; h += 4) {        // four scalars in flight at a time: eight would cost a wave of occupancy
-                fe s4[4];
-#pragma unroll
-                for (int b = 0; b < 4; b++) s4[b] = scalar_of(k + h + b);
-                int32_t w3 = h ? 81 : 1;            // 3^(h+b)
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    uint32_t z = 0, o = 0, m = 0;   // == 0, == 1, == -1 (Montgomery images when the scalars are)
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const uint32_t one = a.scalars_mont ? FrParams::one(i) : (i == 0 ? 1u : 0u);
-                        z |= s4[b].l[i]; o |= s4[b].l[i] ^ one; m |= s4[b].l[i] ^ minus_one.l[i];
-                    }
-                    ok = ok && (z == 0 || o == 0 || m == 0);
-                    v += o == 0 ? w3 : (m == 0 ? -w3 : 0);
-                    w3 *= 3;
-                }
-            }
-            const size_t grp = (k - bit0) >> 3;
-            if (__all(ok) && uni(a.group_ok[grp])) {
-                if (v) {
-                    const uint32_t idx = (uint32_t)(v < 0 ? -v : v) - 1;
-                    const RawAff<F> nxt = load_raw<F>(sub + (grp * MSM_GROUP_ENTRIES + idx) * (2 * F::WORDS));
-                    if (have) acc = C::template madd<EXACT>(acc, unpack_aff(pend, pend_neg));
-                    pend = nxt; pend_neg = v < 0; have = true;
-                }
-                k += 8;
-                continue;
-            }
-            single_until = k + 8; have_next = false;
-        }
-        fe s = have_next ? s_next : scalar_of(k);
-        have_next = k + 1 < k1 && (!BITS || k + 1 < bit0 || k + 1 >= bit1 || k + 1 < single_until);
-        if (have_next) s_next = scalar_of(k + 1);
-        if (a.scalars_mont) s = Fr::from_mont(s);
-        const bool neg = sign_normalise(s);
-        // digit table of this base (wave-uniform): the wide-digit table for the bases predicted to carry full-width scalars
-        const bool wide = BITS && k < a.nwide;
-        const uint32_t c = wide ? (uint32_t)a.c2 : (uint32_t)a.c, nwin = wide ? (uint32_t)a.nwin2 : (uint32_t)a.nwin, D = 1u << (c - 1);
-        const fe* table = reinterpret_cast<const fe*>(wide ? a.table2 : a.table);
-        // number of windows this lane needs: highest set bit / c + 1 (+1 for a possible carry)
-        int top = -1;
-#pragma unroll
-        for (int i = 7; i >= 0; i--) if (top < 0 && s.l[i]) top = 32 * i + 31 - __clz(s.l[i]);
-        uint32_t need = top < 0 ? 0u : (uint32_t)top / c + 2u;
-        if (need > nwin) need = nwin;
-        uint32_t carry = 0;
-        const uint32_t cmask = (1u << c) - 1;
-        for (uint32_t j = 0; j < need; j++) {
-            uint32_t raw = (s.l[0] & cmask) + carry;        // the scalar is shifted down one digit per step: no variable limb indexing
-#pragma unroll
-            for (int i = 0; i < 7; i++) s.l[i] = __builtin_amdgcn_alignbit(s.l[i + 1], s.l[i], c);
-            s.l[7] >>= c;
-            bool dneg = false;
-            if (raw > D) { raw = (1u << c) - raw; dneg = true; carry = 1; } else carry = 0;
-            if (raw) {
-                const RawAff<F> nxt = load_raw<F>(table + (((size_t)k * nwin + j) * D + (raw - 1)) * (2 * F::WORDS));
-                if (have) acc = C::template madd<EXACT>(acc, unpack_aff(pend, pend_neg));
-                pend = nxt; pend_neg = dneg != neg; have = true;
-            }
-        }
-        k++;
-    }
-    if (have) acc = C::template madd<EXACT>(acc, unpack_aff(pend, pend_neg));
-    return acc;
-}
-
-// BITS = false is the instantiation for sets without bit groups (the Z tables: the dominant launch keeps its register budget)
-template <class F, bool BITS>
-__global__ __launch_bounds__(64) void k_msm(MsmArgs a) {
-    using C = Curve9<F>;
-    // XCD-aware order: workgroups go round-robin over the 8 XCDs by linear id, and each XCD has its own L2.  All proof groups of
-    // a slice read the same table rows, so they are placed on ONE XCD (consecutive ids there), not spread over all eight.
-    size_t slice = blockIdx.y, grp = blockIdx.x;
-    {
-        const size_t G = gridDim.x, L = (size_t)blockIdx.y * G + blockIdx.x, S8 = (size_t)gridDim.y & ~(size_t)7;
-        if (L < S8 * G) { const size_t xcd = L & 7, i = L >> 3; slice = (i / G) * 8 + xcd; grp = i % G; }
-    }
-    const size_t p = grp * 64 + threadIdx.x;
-    const size_t per = ((a.nbases + a.nslices - 1) / a.nslices + 7) & ~(size_t)7;      // bit groups never straddle slices
-    const size_t k0 = slice * per < a.nbases ? slice * per : a.nbases, k1 = k0 + per < a.nbases ? k0 + per : a.nbases;
-    Xyzz9<F> acc = accumulate_slice<F, false, BITS>(a, k0, k1, p);
-    // A degenerate step (accumulator == +-entry) zeroes ZZ for good; it cannot be told from a genuine point at infinity
-    // without the exact tests, so the (very rare) lane is recomputed with them.
-    if (!acc.inf && F::is_zero(acc.zz)) acc = accumulate_slice<F, true, BITS>(a, k0, k1, p);
-    C::store_xyzz(reinterpret_cast<fe*>(a.partial) + (slice * a.batch + p) * (4 * F::WORDS), acc);
 }
 
 __device__ __forceinline__ fe9 shfl_xor_e(const fe9& v, int m) {
@@ -315,14 +171,6 @@ __global__ void k_challenge_from_hash(const uint8_t* h48, fe* commit, size_t bat
 
 }  // namespace
 
-void launch_msm_g1(const MsmArgs& a, hipStream_t s) {
-    if (a.nbit) hipLaunchKernelGGL((k_msm<Fp29f, true>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_msm<Fp29f, false>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
-}
-void launch_msm_g2(const MsmArgs& a, hipStream_t s) {
-    if (a.nbit) hipLaunchKernelGGL((k_msm<Fp2x, true>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_msm<Fp2x, false>), dim3((unsigned)(a.batch / 64), (unsigned)a.nslices), dim3(64), 0, s, a);
-}
 // returns the number of partial sums left per proof (1 = done)
 template <class F>
 static size_t launch_msm_reduce(const fe* partial, size_t nslices, size_t batch, fe* out, hipStream_t s) {

@@ -1,17 +1,23 @@
-// Fixed-base multi-scalar multiplication with ONE table per base and one accumulator per window.
+// Fixed-base multi-scalar multiplication for a batch of independent proofs that share the proving key.
 //
 // Replaces (*G1Jac).MultiExp / (*G2Jac).MultiExp of groth16.Prove (reference libraries/prover/impl/provers.go:148,216;
-// SURVEY.md §8(a) a9/a10, algebra App. D) for a batch of independent proofs that share the proving key.
+// SURVEY.md §8(a) a9/a10, algebra App. D).  Bases are fixed for the life of the process, so every base has ONE table row
+// T_k[d-1] = d * P_k in HBM and an MSM is a gather-accumulate; lanes of a wave are 64 proofs working on the same base, so scalar
+// digits are read coalesced and the gathers of a wave fall into one row.
 //
-//   T[k][d-1] = d * P_k,  d = 1 .. D = 2^(c-1)                      (InitAlgorithm, k_build_base_table below)
-//   s_k = sum_j e_kj 2^(c j),  e_kj in [-D, D-1]                     (k_recode: signed digits, once per batch)
-//   S_j = sum_k sign(e_kj) T[k][|e_kj|-1]                            (k_msm_win: one wave per (slice of bases, window j, 64 proofs))
-//   sum_k s_k P_k = sum_j 2^(c j) S_j                                (k_msm_horner: c doublings + one addition per window)
+// Full-width scalars (the quotient h over pk.G1.Z; the few wide wires of a wire set) — "windowed":
+//   s_k = sum_j e_kj 2^(c j),  e_kj in [-D, D-1], D = 2^(c-1)          (k_recode: signed digits, once per batch)
+//   S_j = sum_k sign(e_kj) T_k[|e_kj|-1]                                (k_msm_win: one wave per (slice of bases, window j, 64 proofs))
+//   sum_k s_k P_k = sum_j 2^(c j) S_j                                   (k_msm_horner: c doublings + one addition per window)
+// The same number of additions as a table per (base, window) with nwin times less HBM, which is spent on wider digits instead
+// (fewer windows = fewer additions).  All waves of a slice (every window, every group of proofs) read the same rows and are
+// placed on ONE XCD so that they share them in its L2.
 //
-// The same number of additions as a table per (base, window), with nwin times less HBM, which is spent on wider digits
-// instead (fewer windows = fewer additions).  Lanes of a wave are 64 proofs working on the same base, so digit loads are
-// coalesced and the table gathers of a wave fall into one row of D * 64 bytes; all waves of a slice (every window, every
-// group of proofs) read the same rows and are placed on ONE XCD so that they share them in its L2.
+// Small scalars (nearly every wire of these circuits: bits, values in {-1, 0, 1}, bytes) — "flat":
+//   one signed 16-bit value per (base, proof), one accumulator, one wave per (slice of bases, 64 proofs)     (k_recode_flat, k_msm_flat)
+//   eight ternary wires at a time through a table of their signed subset sums; rows only as long as the wire was seen to need.
+// Both are predictions made at InitAlgorithm and checked for every wave of proofs: a scalar that does not fit is multiplied out
+// by double-and-add, so results never depend on the prediction.
 #include "kernels.hpp"
 #include "bn254_fp29.hpp"
 
@@ -40,7 +46,7 @@ __device__ __forceinline__ bool sign_normalise(fe& s) {
     return gt;
 }
 
-// ---- signed-digit recoding -------------------------------------------------------------------------------------------------
+// ---- signed-digit recoding (windowed sets) --------------------------------------------------------------------------------------
 // One thread per (octet of bases, proof): eight scalars -> for every window one 16-byte word of eight int16 digits.
 // digits[(j * noct + o) * batch + p] = {e_{8o,j}, ..., e_{8o+7,j}} of proof p.  MONT: the scalars are Montgomery residues of wire
 // values (sign-normalised first: wires are mostly tiny or -tiny); otherwise canonical integers below r (the quotient h).
@@ -79,6 +85,73 @@ __global__ __launch_bounds__(64) void k_recode(MsmRecodeArgs a) {
     }
 }
 
+// ---- recoding of a flat set ------------------------------------------------------------------------------------------------------
+// One thread per (octet of bases, proof) -> ONE 16-byte word of eight int16 values, digits[o * batch + p].  Three kinds of octets:
+//  * bit groups (o < nbit / 8): the eight wires are predicted to carry scalars in {-1, 0, 1}; they form a balanced-ternary number
+//    v = sum t_i 3^i and ONE addition of the tabulated signed subset sum replaces up to eight.  Every wave checks the prediction
+//    (all eight scalars ternary for all 64 proofs; group_ok[o]: the group's subset sums could be tabulated) and says so in
+//    gok[o][wave]: 1 = slot 0 carries v; 0 = ordinary values, the eight bases are walked one by one;
+//  * ordinary octets: slot i = the sign-normalised scalar of base 8o + i if it fits 15 bits, else MSM_FLAT_ESCAPE (the MSM kernel
+//    then multiplies that scalar out by double-and-add: a wrong prediction costs time, never correctness);
+//  * window octets (octwin[o] >= 0): slots = the signed c-bit digits octwin[o] .. octwin[o] + 7 of the ONE scalar rows[8o]: a wide
+//    wire whose (base, window) pairs were laid out as bases of their own, with the points 2^(c j) P (tiny wide sets: no Horner pass).
+__global__ __launch_bounds__(64) void k_recode_flat(MsmFlatRecodeArgs a) {
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x, o = blockIdx.y;
+    const int32_t win0 = a.octwin ? (int32_t)uni((uint32_t)a.octwin[o]) : -1;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (win0 >= 0) {
+        fe s = Fr::from_mont(load_fe(a.scalars + (size_t)uni(a.rows[8 * o]) * a.batch + p));
+        const bool ng = sign_normalise(s);
+        const uint32_t c = (uint32_t)a.c, cmask = (1u << c) - 1, D = 1u << (c - 1);
+        uint32_t carry = 0;
+        for (int32_t j = 0; j < win0 + 8; j++) {                    // digits below win0 are recomputed for their carry only
+            uint32_t raw = (s.l[0] & cmask) + carry;
+#pragma unroll
+            for (int q = 0; q < 7; q++) s.l[q] = __builtin_amdgcn_alignbit(s.l[q + 1], s.l[q], c);
+            s.l[7] >>= c;
+            int32_t d = (int32_t)raw;
+            if (raw >= D + (ng ? 1u : 0u)) { d -= (int32_t)(1u << c); carry = 1; } else carry = 0;
+            if (ng) d = -d;
+            if (j >= win0) { const int i = j - win0; w[i >> 1] |= ((uint32_t)d & 0xFFFFu) << (16 * (i & 1)); }
+        }
+        a.digits[o * a.batch + p] = make_uint4(w[0], w[1], w[2], w[3]);
+        return;
+    }
+    fe s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const size_t k = 8 * o + i;
+        s[i] = k < a.nbases ? load_fe(a.scalars + (size_t)uni(a.rows[k]) * a.batch + p) : fe{};
+    }
+    if (o < a.nbit / 8) {
+        const fe minus_one = Fr::neg(Fr::one());
+        int32_t v = 0, w3 = 1; bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t z = 0, e1 = 0, m1 = 0;   // == 0, == 1, == -1 (Montgomery images)
+#pragma unroll
+            for (int q = 0; q < 8; q++) { z |= s[i].l[q]; e1 |= s[i].l[q] ^ FrParams::one(q); m1 |= s[i].l[q] ^ minus_one.l[q]; }
+            ok = ok && (z == 0 || e1 == 0 || m1 == 0);
+            v += e1 == 0 ? w3 : (m1 == 0 ? -w3 : 0);
+            w3 *= 3;
+        }
+        const bool all_ok = __all(ok) && uni(a.group_ok[o]) != 0;
+        if (threadIdx.x == 0) a.gok[o * (a.batch / 64) + blockIdx.x] = all_ok ? 1 : 0;
+        if (all_ok) { a.digits[o * a.batch + p] = make_uint4((uint32_t)v & 0xFFFFu, 0, 0, 0); return; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        s[i] = Fr::from_mont(s[i]);
+        const bool ng = sign_normalise(s[i]);
+        uint32_t hi = s[i].l[0] >> 15;
+#pragma unroll
+        for (int q = 1; q < 8; q++) hi |= s[i].l[q];
+        const int32_t d = hi ? MSM_FLAT_ESCAPE : (ng ? -(int32_t)s[i].l[0] : (int32_t)s[i].l[0]);
+        w[i >> 1] |= ((uint32_t)d & 0xFFFFu) << (16 * (i & 1));
+    }
+    a.digits[o * a.batch + p] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // ---- gather-accumulate -------------------------------------------------------------------------------------------------------
 template <class F> struct RawAff { fe w[2 * F::WORDS]; };
 template <class F> __device__ __forceinline__ RawAff<F> load_raw(const fe* p) {
@@ -101,7 +174,7 @@ __device__ __forceinline__ Aff9<Fp2x> unpack_aff(const RawAff<Fp2x>& r, bool neg
 // Bases [k0, k1) of window j for one proof (lane).  EXACT = false is the hot path (no degenerate-case tests inside madd).
 // Software pipelining: the digits of the NEXT octet of bases and the table entry of the NEXT base are requested before the
 // current mixed addition (~2 300 instructions) starts, so neither the coalesced digit stream nor the 64-byte random gathers
-// are on the critical path.
+// are on the critical path.  Uniform rows: entry d - 1 of base k is table[k * D + d - 1].
 template <class F, bool EXACT>
 __device__ __forceinline__ Xyzz9<F> accumulate_window(const MsmWinArgs& a, size_t k0, size_t k1, uint32_t j, size_t p) {
     using C = Curve9<F>;
@@ -162,9 +235,101 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArg
     C::store_xyzz(reinterpret_cast<fe*>(a.partial) + ((slice * a.nwin + j) * a.batch + p) * (4 * F::WORDS), acc);
 }
 
-// out[p] = sum_j 2^(c j) S[j][p]: Horner from the top window, lanes = proofs.  254 doublings per proof whatever the width.
+// ---- flat sets ----------------------------------------------------------------------------------------------------------------------
+// Bases [k0, k1) of a flat set for one proof (lane): see k_recode_flat for the three kinds of octets.  Rows have a length of their
+// own (rowlen[k] multiples of P_k at entry rowoff[k]); a value beyond its row, or MSM_FLAT_ESCAPE, is multiplied out by
+// double-and-add from the row's first entry.
+template <class F, bool EXACT>
+__device__ __forceinline__ Xyzz9<F> accumulate_flat(const MsmFlatArgs& a, size_t k0, size_t k1, size_t g, size_t p) {
+    using C = Curve9<F>;
+    const size_t G = a.batch / 64, o0 = k0 / 8, o1 = (k1 + 7) / 8, nbit8 = a.nbit / 8;
+    const fe* table = reinterpret_cast<const fe*>(a.table);
+    const fe* sub = reinterpret_cast<const fe*>(a.sub);
+    const uint32_t lane = threadIdx.x;
+    uint64_t okmask = 0;                                    // bit i: octet o0 + i is a group that passed k_recode_flat's check for this wave
+    if (o0 < nbit8) { const size_t o = o0 + lane; const uint32_t f = (o < o1 && o < nbit8) ? a.gok[o * G + g] : 0u; okmask = __ballot(f != 0); }
+    const uint4* dig = a.digits + o0 * a.batch + p;
+    Xyzz9<F> acc = C::infinity();
+    RawAff<F> pend = {}; int32_t dp = 0;
+    uint4 cur = *dig;
+    // row geometry of an octet's bases: lane i < 8 holds (offset, length) of base 8 o + i; fetched one octet ahead
+    uint32_t roff_lo = 0, roff_hi = 0, rlen = 0;
+    auto load_rows = [&](size_t o) {
+        const size_t k = 8 * o + (lane & 7);
+        const uint64_t off = k < a.nbases ? a.rowoff[k] : 0; roff_lo = (uint32_t)off; roff_hi = (uint32_t)(off >> 32); rlen = k < a.nbases ? a.rowlen[k] : 0u;
+    };
+    load_rows(o0);
+    for (size_t o = o0; o < o1; o++) {
+        dig += a.batch;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        const uint32_t c_lo = roff_lo, c_hi = roff_hi, c_len = rlen;
+        if (o + 1 < o1) { nxt = *dig; load_rows(o + 1); }
+        const bool grp = o < nbit8 && ((okmask >> (o - o0)) & 1);                                   // wave-uniform
+        const uint64_t lo = (uint64_t)cur.x | ((uint64_t)cur.y << 32), hi = (uint64_t)cur.z | ((uint64_t)cur.w << 32);
+        const uint32_t lim = grp ? 1u : (k1 - 8 * o < 8 ? (uint32_t)(k1 - 8 * o) : 8u);
+#pragma unroll 1
+        for (uint32_t i = 0; i < lim; i++) {
+            int32_t d = (int32_t)(int16_t)(uint16_t)(((i & 4) ? hi : lo) >> (16 * (i & 3)));
+            int32_t mag = d < 0 ? -d : d;
+            const fe* src;
+            if (grp) src = sub + (o * MSM_GROUP_ENTRIES + (size_t)(mag ? mag - 1 : 0)) * (2 * F::WORDS);
+            else {
+                const uint64_t off = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)c_lo, (int)i) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)c_hi, (int)i) << 32);
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)c_len, (int)i);
+                const bool beyond = (uint32_t)mag > len;                                            // MSM_FLAT_ESCAPE has magnitude 32768 > any flat row
+                if (__any(beyond)) {                                                                // wrong prediction: rare, slow, exact
+                    if (beyond) {
+                        fe sc = fe{}; bool sneg = d < 0;
+                        if (d == MSM_FLAT_ESCAPE) { sc = Fr::from_mont(load_fe(a.scalars + (size_t)a.rows[8 * o + i] * a.batch + p)); sneg = sign_normalise(sc); }
+                        else sc.l[0] = (uint32_t)mag;
+                        const Aff9<F> P1 = unpack_aff(load_raw<F>(table + off * (2 * F::WORDS)), sneg);
+                        Xyzz9<F> Q = C::infinity();
+                        for (int b = 253; b >= 0; b--) {
+                            if (!Q.inf) Q = C::dbl(Q);
+                            uint32_t word = sc.l[0];
+#pragma unroll
+                            for (int q = 1; q < 8; q++) word = (b >> 5) == q ? sc.l[q] : word;
+                            if ((word >> (b & 31)) & 1u) Q = C::template madd<true>(Q, P1);
+                        }
+                        acc = C::add(acc, Q);
+                        d = 0; mag = 0;
+                    }
+                }
+                src = table + (off + (size_t)(mag ? mag - 1 : 0)) * (2 * F::WORDS);
+            }
+            const RawAff<F> e = load_raw<F>(src);
+            if (dp) acc = C::template madd<EXACT>(acc, unpack_aff(pend, dp < 0));
+            pend = e; dp = d;
+        }
+        cur = nxt;
+    }
+    if (dp) acc = C::template madd<EXACT>(acc, unpack_aff(pend, dp < 0));
+    return acc;
+}
+
+// grid: nslices * (batch / 64) workgroups of one wave.  partial[slice * batch + p]
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_horner(const fe* S, int nwin, int c, size_t batch, fe* out) {
+__global__ __launch_bounds__(64, F::WORDS == 1 ? 2 : 1) void k_msm_flat(MsmFlatArgs a) {
+    using C = Curve9<F>;
+    const size_t G = a.batch / 64, L = blockIdx.x, S8 = a.nslices & ~(size_t)7;
+    size_t slice, g;                                        // all groups of proofs of a slice on one XCD (see k_msm_win)
+    if (L < S8 * G) { const size_t xcd = L & 7, i = L >> 3; slice = (i / G) * 8 + xcd; g = i % G; }
+    else { slice = L / G; g = L % G; }
+    const size_t p = g * 64 + threadIdx.x;
+    const size_t k0 = slice * a.per < a.nbases ? slice * a.per : a.nbases, k1 = k0 + a.per < a.nbases ? k0 + a.per : a.nbases;
+    Xyzz9<F> acc = C::infinity();
+    if (k0 < k1) {
+        acc = accumulate_flat<F, false>(a, k0, k1, g, p);
+        // (see k_msm_win)  The repair runs with ALL lanes of the wave: accumulate_flat uses __ballot / readlane, which need them.
+        const bool bad = !acc.inf && F::is_zero(acc.zz);
+        if (__any(bad)) { const Xyzz9<F> fix = accumulate_flat<F, true>(a, k0, k1, g, p); if (bad) acc = fix; }
+    }
+    C::store_xyzz(reinterpret_cast<fe*>(a.partial) + (slice * a.batch + p) * (4 * F::WORDS), acc);
+}
+
+// out[p] = sum_j 2^(c j) S[j][p] (+ addend[p]): Horner from the top window, lanes = proofs.  254 doublings per proof whatever the width.
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_horner(const fe* S, int nwin, int c, size_t batch, const fe* addend, fe* out) {
     using C = Curve9<F>;
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     Xyzz9<F> r = C::load_xyzz(S + ((size_t)(nwin - 1) * batch + p) * (4 * F::WORDS));
@@ -173,10 +338,10 @@ __global__ __launch_bounds__(64) void k_msm_horner(const fe* S, int nwin, int c,
         for (int q = 0; q < c; q++) r = C::dbl(r);
         r = C::add(r, C::load_xyzz(S + ((size_t)j * batch + p) * (4 * F::WORDS)));
     }
+    if (addend) r = C::add(r, C::load_xyzz(addend + p * (4 * F::WORDS)));
     C::store_xyzz(out + p * (4 * F::WORDS), r);
 }
 
-// ---- InitAlgorithm: T[k][d-1] = d * P_k ----------------------------------------------------------------------------------------
 // Montgomery value of the 8 x 32-bit domain (R = 2^256, what the decompression kernels produce) -> radix-2^29 domain (R' = 2^261)
 __device__ __forceinline__ fe9 to_fp29(const fe& old_mont) { return Fp29::to_mont(Fp29::unpack(Fp::from_mont(old_mont))); }
 __device__ __forceinline__ Aff9<Fp29f> base_to_fp29(const Aff<Fp>* b) { return Aff9<Fp29f>{to_fp29(b->x), to_fp29(b->y)}; }
@@ -184,33 +349,50 @@ __device__ __forceinline__ Aff9<Fp2x> base_to_fp29(const Aff<Fp2>* b) {
     return Aff9<Fp2x>{fe9x2{to_fp29(b->x.a0), to_fp29(b->x.a1)}, fe9x2{to_fp29(b->y.a0), to_fp29(b->y.a1)}};
 }
 
-// One thread per segment of `seg` consecutive multiples of one base: the first multiple by double-and-add, the rest by mixed
-// additions, kept in XYZZ in `scratch` with the running product of the ZZZ parked in the table slots; one inversion per
-// segment turns them into affine entries (Montgomery batch inversion).  Threads [t0, t0 + nthreads) of the (base, segment)
-// grid are processed by one launch; scratch holds nthreads * seg points.
+// and back
+__device__ __forceinline__ fe from_fp29_fe(const fe9& m) { return Fp::to_mont(Fp29::pack(Fp29::from_mont(m))); }
+__device__ __forceinline__ Aff<Fp> from_fp29(const Aff9<Fp29f>& a) { return Aff<Fp>{from_fp29_fe(a.x), from_fp29_fe(a.y)}; }
+__device__ __forceinline__ Aff<Fp2> from_fp29(const Aff9<Fp2x>& a) { return Aff<Fp2>{fe2{from_fp29_fe(a.x.a0), from_fp29_fe(a.x.a1)}, fe2{from_fp29_fe(a.y.a0), from_fp29_fe(a.y.a1)}}; }
+
+// out[i] = 2^shift[i] * in[src[i]] (affine, 8 x 32-bit Montgomery images like the decompression kernels' output): the points of the
+// (base, window) pairs of a wide wire laid out as bases of their own.
 template <class F, class OldF>
-__global__ __launch_bounds__(64) void k_build_base_table(const Aff<OldF>* bases, size_t t0, size_t nthreads, int c, uint32_t seg, fe* table, fe* scratch) {
+__global__ __launch_bounds__(64) void k_shift_bases(const Aff<OldF>* in, const uint32_t* src, const uint32_t* shift, size_t n, Aff<OldF>* out) {
+    using C = Curve9<F>;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xyzz9<F> P = C::from_aff(base_to_fp29(in + src[i]));
+    for (uint32_t q = 0; q < shift[i]; q++) P = C::dbl(P);
+    const Aff9<F> A = C::to_aff(P);
+    out[i] = from_fp29(A);
+}
+
+// ---- InitAlgorithm: T[k][d-1] = d * P_k ----------------------------------------------------------------------------------------
+// One thread per segment (MsmRowSeg) of up to `cap` consecutive multiples of one base: the first multiple by double-and-add, the
+// rest by mixed additions, kept in XYZZ in `scratch` with the running product of the ZZZ parked in the table slots; one inversion
+// per segment turns them into affine entries (Montgomery batch inversion).  scratch holds nsegs * cap points.
+template <class F, class OldF>
+__global__ __launch_bounds__(64) void k_build_rows(const Aff<OldF>* bases, const MsmRowSeg* segs, size_t nsegs, uint32_t cap, fe* table, fe* scratch) {
     using C = Curve9<F>;
     using E = typename F::E;
     constexpr int CW = F::WORDS;
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= nthreads) return;
-    const size_t D = (size_t)1 << (c - 1), segs = D / seg, id = t0 + t, k = id / segs, q = id % segs;
-    const Aff9<F> P = base_to_fp29(bases + k);
-    const uint32_t d0 = (uint32_t)(q * seg + 1);
+    if (t >= nsegs) return;
+    const MsmRowSeg sg = segs[t];
+    const Aff9<F> P = base_to_fp29(bases + sg.base);
     Xyzz9<F> Ed = C::infinity();
-    for (int b = 31 - __clz(d0); b >= 0; b--) { Ed = C::dbl(Ed); if ((d0 >> b) & 1u) Ed = C::template madd<true>(Ed, P); }
-    fe* out = table + (k * D + (d0 - 1)) * (2 * CW);
-    fe* sc = scratch + t * seg * (4 * CW);
+    for (int b = 31 - __clz(sg.first); b >= 0; b--) { Ed = C::dbl(Ed); if ((sg.first >> b) & 1u) Ed = C::template madd<true>(Ed, P); }
+    fe* out = table + sg.entry * (2 * CW);
+    fe* sc = scratch + t * cap * (4 * CW);
     E prefix = F::one();
-    for (uint32_t d = 0; d < seg; d++) {
+    for (uint32_t d = 0; d < sg.count; d++) {
         if (d) Ed = C::template madd<true>(Ed, P);
         C::store_xyzz(sc + d * (4 * CW), Ed);
         F::store(out + d * (2 * CW), prefix);                       // product of the ZZZ before this entry
         prefix = F::mul(prefix, Ed.zzz);
     }
     E inv = F::inv(prefix);
-    for (uint32_t d = seg; d-- > 0;) {
+    for (uint32_t d = sg.count; d-- > 0;) {
         Ed = C::load_xyzz(sc + d * (4 * CW));
         const E pre = F::load(out + d * (2 * CW));
         const E izzz = F::mul(inv, pre);                             // 1 / ZZZ_d
@@ -229,25 +411,32 @@ void launch_msm_recode(const MsmRecodeArgs& a, hipStream_t s) {
     if (a.mont) hipLaunchKernelGGL(k_recode<true>, grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_recode<false>, grid, dim3(64), 0, s, a);
 }
-void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_win<Fp29f>, dim3((unsigned)(a.nslices * a.nwin * (a.batch / 64))), dim3(64), 0, s, a);
+void launch_msm_recode_flat(const MsmFlatRecodeArgs& a, hipStream_t s) {
+    if (a.nbases) hipLaunchKernelGGL(k_recode_flat, dim3((unsigned)(a.batch / 64), (unsigned)((a.nbases + 7) / 8)), dim3(64), 0, s, a);
 }
-void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_win<Fp2x>, dim3((unsigned)(a.nslices * a.nwin * (a.batch / 64))), dim3(64), 0, s, a);
+void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_win<Fp29f>, dim3((unsigned)(a.nslices * a.nwin * (a.batch / 64))), dim3(64), 0, s, a); }
+void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_win<Fp2x>, dim3((unsigned)(a.nslices * a.nwin * (a.batch / 64))), dim3(64), 0, s, a); }
+void launch_msm_flat_g1(const MsmFlatArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat<Fp29f>, dim3((unsigned)(a.nslices * (a.batch / 64))), dim3(64), 0, s, a); }
+void launch_msm_flat_g2(const MsmFlatArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat<Fp2x>, dim3((unsigned)(a.nslices * (a.batch / 64))), dim3(64), 0, s, a); }
+void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, const G1Xyzz* addend, G1Xyzz* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_msm_horner<Fp29f>, dim3((unsigned)(batch / 64)), dim3(64), 0, s, reinterpret_cast<const fe*>(S), nwin, c, batch, reinterpret_cast<const fe*>(addend), reinterpret_cast<fe*>(out));
 }
-void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, G1Xyzz* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_horner<Fp29f>, dim3((unsigned)(batch / 64)), dim3(64), 0, s, reinterpret_cast<const fe*>(S), nwin, c, batch, reinterpret_cast<fe*>(out));
+void launch_msm_horner_g2(const G2Xyzz* S, int nwin, int c, size_t batch, const G2Xyzz* addend, G2Xyzz* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_msm_horner<Fp2x>, dim3((unsigned)(batch / 64)), dim3(64), 0, s, reinterpret_cast<const fe*>(S), nwin, c, batch, reinterpret_cast<const fe*>(addend), reinterpret_cast<fe*>(out));
 }
-void launch_msm_horner_g2(const G2Xyzz* S, int nwin, int c, size_t batch, G2Xyzz* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_horner<Fp2x>, dim3((unsigned)(batch / 64)), dim3(64), 0, s, reinterpret_cast<const fe*>(S), nwin, c, batch, reinterpret_cast<fe*>(out));
+void launch_build_rows_g1(const G1Aff* bases, const MsmRowSeg* segs, size_t nsegs, uint32_t cap, G1Aff* table, G1Xyzz* scratch, hipStream_t s) {
+    if (nsegs) hipLaunchKernelGGL((k_build_rows<Fp29f, Fp>), dim3((unsigned)((nsegs + 63) / 64)), dim3(64), 0, s,
+                                  reinterpret_cast<const Aff<Fp>*>(bases), segs, nsegs, cap, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
 }
-void launch_build_base_table_g1(const G1Aff* bases, size_t t0, size_t nthreads, int c, uint32_t seg, G1Aff* table, G1Xyzz* scratch, hipStream_t s) {
-    if (nthreads) hipLaunchKernelGGL((k_build_base_table<Fp29f, Fp>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s,
-                                     reinterpret_cast<const Aff<Fp>*>(bases), t0, nthreads, c, seg, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
+void launch_build_rows_g2(const G2Aff* bases, const MsmRowSeg* segs, size_t nsegs, uint32_t cap, G2Aff* table, G2Xyzz* scratch, hipStream_t s) {
+    if (nsegs) hipLaunchKernelGGL((k_build_rows<Fp2x, Fp2>), dim3((unsigned)((nsegs + 63) / 64)), dim3(64), 0, s,
+                                  reinterpret_cast<const Aff<Fp2>*>(bases), segs, nsegs, cap, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
 }
-void launch_build_base_table_g2(const G2Aff* bases, size_t t0, size_t nthreads, int c, uint32_t seg, G2Aff* table, G2Xyzz* scratch, hipStream_t s) {
-    if (nthreads) hipLaunchKernelGGL((k_build_base_table<Fp2x, Fp2>), dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, s,
-                                     reinterpret_cast<const Aff<Fp2>*>(bases), t0, nthreads, c, seg, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch));
+void launch_shift_bases_g1(const G1Aff* in, const uint32_t* src, const uint32_t* shift, size_t n, G1Aff* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL((k_shift_bases<Fp29f, Fp>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, reinterpret_cast<const Aff<Fp>*>(in), src, shift, n, reinterpret_cast<Aff<Fp>*>(out));
+}
+void launch_shift_bases_g2(const G2Aff* in, const uint32_t* src, const uint32_t* shift, size_t n, G2Aff* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL((k_shift_bases<Fp2x, Fp2>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, reinterpret_cast<const Aff<Fp2>*>(in), src, shift, n, reinterpret_cast<Aff<Fp2>*>(out));
 }
 
 }  // namespace gsc

@@ -23,10 +23,6 @@ void launch_decompress_g2(const uint8_t* in, G2Aff* out, uint8_t* status, size_t
 // canonical big-endian Fr -> Montgomery limbs
 void launch_fr_from_be(const uint8_t* in, fe* out, size_t n, hipStream_t s);
 void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s);
-// Fixed-base digit tables: table[(k*nwin + j)*D + (d-1)] = d * 2^(c*j) * base[k],  D = 2^(c-1), affine.
-// Builds table rows [row0, row0 + nrows) (row = k*nwin + j); scratch: nrows * D projective points.
-void launch_build_table_g1(const G1Aff* bases, size_t row0, size_t nrows, int c, int nwin, G1Aff* table, G1Xyzz* scratch, hipStream_t s);
-void launch_build_table_g2(const G2Aff* bases, size_t row0, size_t nrows, int c, int nwin, G2Aff* table, G2Xyzz* scratch, hipStream_t s);
 // NTT constants for a domain of size 2^L: tw_fwd[i] = w^i, tw_inv[i] = w^-i (i < n/2, Montgomery);
 // scale_mid[pos] = n^-1 * g^bitrev(pos) (Montgomery); scale_out[pos] = n^-1 * g^-bitrev(pos) (plain, so that the
 // Montgomery product with it leaves the result in canonical form).
@@ -63,10 +59,6 @@ void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStr
 // *flag |= 1 if some OP_COUNT table's index column is not 0,1,2,... (InitAlgorithm-time validation)
 void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s);
 
-constexpr uint32_t MSM_GROUP_ENTRIES = 3280;      // (3^8 - 1) / 2
-void launch_build_subset_g1(const G1Aff* bases, size_t ngroups, G1Aff* table, G1Xyzz* scratch, uint8_t* ok, hipStream_t s);
-void launch_build_subset_g2(const G2Aff* bases, size_t ngroups, G2Aff* table, G2Xyzz* scratch, uint8_t* ok, hipStream_t s);
-
 // Calibration: cls[w] = 0 if wire w is 0 or 1 in every accepted proof of the batch (status == 0xFFFFFFFF), otherwise the largest bit
 // length of its sign-normalised value (1 = the wire also takes -1, .. 254).  W: [n_wires][batch] Montgomery.
 void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint32_t* status, uint8_t* cls, hipStream_t s);
@@ -81,42 +73,24 @@ constexpr int NTT_MIN_LOG2 = 15, NTT_MAX_LOG2 = 17;
 // Returns the first launch-configuration error (nothing is launched when the domain is unsupported).
 hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s);
 
-// ---- multi-scalar multiplication (k_msm.hip) ----
-// partial[slice * batch + proof] = sum over bases k in slice of scalar[rows[k]][proof] * base_k
-struct MsmArgs {
-    const void* table; int c; int nwin; size_t nbases;
-    const uint32_t* rows;          // scalar row per base (nullptr: row k)
-    const fe* scalars;             // [row][batch]
-    int scalars_mont;              // 1: Montgomery form, 0: canonical
-    size_t batch; size_t nslices;  // slices of ceil(nbases/nslices) consecutive bases, rounded up to a multiple of 8
-    void* partial;                 // G1Xyzz / G2Xyzz [nslices][batch]
-    // Layout of a wire set, predicted at InitAlgorithm (never trusted for correctness):
-    //   bases [0, nwide)            full-width scalars: a second digit table with wider digits (table2, c2, nwin2; base index k)
-    //   bases [nwide, nwide + nbit) scalars that are -1, 0 or 1 in nearly every proof (nwide, nbit multiples of 8): group g = bases
-    //                               nwide+8g .. +7 has a table of signed subset sums sub[g][v-1] = sum_i t_i * base_i for the balanced-ternary
-    //                               value v = sum_i t_i 3^i > 0 (MSM_GROUP_ENTRIES affine entries; v < 0 is the negated entry), group_ok[g] != 0
-    //   the rest                    everything else, through `table`
-    size_t nbit; const void* sub; const uint8_t* group_ok;
-    size_t nwide; const void* table2; int c2, nwin2;
-};
-void launch_msm_g1(const MsmArgs& a, hipStream_t s);
-void launch_msm_g2(const MsmArgs& a, hipStream_t s);
-// One reduction level: out[g][proof] = sum of the partials of group g of slices; returns the number of groups (1 = out[proof] is the
-// final sum).  Groups hold 64 slices (butterfly over lanes, small batches) or MSM_REDUCE_FANIN (lanes = proofs, large batches), so
-// `out` must have room for ceil(nslices / MSM_REDUCE_FANIN) * batch points; it must not alias `partial`.
-constexpr size_t MSM_REDUCE_FANIN = 32;
-inline bool msm_reduce_by_proof(size_t nslices, size_t batch) { return (batch / 64) * ((nslices + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN) >= 128; }   // by-proof does 8x less work; the butterfly only wins when there are too few (proof group, chunk) waves
-inline size_t msm_reduce_groups(size_t nslices, size_t batch) { const size_t f = msm_reduce_by_proof(nslices, batch) ? MSM_REDUCE_FANIN : 64; return (nslices + f - 1) / f; }
-size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
-size_t launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
-// ---- windowed MSM over one table per base (k_msm_win.hip) ----
-// table[k * D + (d - 1)] = d * base[k], d = 1 .. D = 2^(c-1), affine.  Built by threads (base, segment of `seg` entries; seg divides D);
-// one launch covers threads [t0, t0 + nthreads) of that grid and needs nthreads * seg projective scratch points.
-void launch_build_base_table_g1(const G1Aff* bases, size_t t0, size_t nthreads, int c, uint32_t seg, G1Aff* table, G1Xyzz* scratch, hipStream_t s);
-void launch_build_base_table_g2(const G2Aff* bases, size_t t0, size_t nthreads, int c, uint32_t seg, G2Aff* table, G2Xyzz* scratch, hipStream_t s);
-// Signed-digit recoding of the scalars of one MSM, once per batch: digits[(j * noct + o) * batch + p] holds the eight int16 digits
-// e_{8o..8o+7, j} in [-D, D-1] of proof p (noct = ceil(nbases / 8); bases beyond nbases get zero digits).  nwin is chosen by the
-// host so that the top window never overflows (msm_windows below).
+// ---- multi-scalar multiplication (k_msm_win.hip, k_msm.hip) ----
+// Every MSM of the prover is a fixed-base sum over a set of the proving key (A, B1, B2, K, Z, commitment bases) for a batch of
+// independent proofs.  Each base has ONE table row of multiples, T_k[d - 1] = d * P_k (affine).  Two kernels (k_msm_win.hip):
+//   windowed: full-width scalars.  sum_k s_k P_k = sum_j 2^(c j) S_j,  S_j = sum_k sign(e_kj) T_k[|e_kj| - 1], signed c-bit digits
+//             e_kj in [-D, D-1], D = 2^(c-1); rows are uniform: row k = entries [k * D, (k + 1) * D).
+//   flat:     small scalars (bits, ternary values, bytes — nearly every wire).  One signed 16-bit value per (base, proof), one
+//             accumulator; rows have their own length rowlen[k] at entry rowoff[k]; bit groups of eight bases share a table of signed
+//             subset sums.
+struct MsmRowSeg { uint32_t base, first, count, pad; uint64_t entry; };     // build work item: `count` multiples of base, from `first`, written at table entry `entry`
+// Builds the rows described by segs (each at most `cap` entries); scratch: nsegs * cap projective points.
+void launch_build_rows_g1(const G1Aff* bases, const MsmRowSeg* segs, size_t nsegs, uint32_t cap, G1Aff* table, G1Xyzz* scratch, hipStream_t s);
+void launch_build_rows_g2(const G2Aff* bases, const MsmRowSeg* segs, size_t nsegs, uint32_t cap, G2Aff* table, G2Xyzz* scratch, hipStream_t s);
+// out[i] = 2^shift[i] * in[src[i]]
+void launch_shift_bases_g1(const G1Aff* in, const uint32_t* src, const uint32_t* shift, size_t n, G1Aff* out, hipStream_t s);
+void launch_shift_bases_g2(const G2Aff* in, const uint32_t* src, const uint32_t* shift, size_t n, G2Aff* out, hipStream_t s);
+
+// Windowed sets.  Signed-digit recoding once per batch: digits[(j * noct + o) * batch + p] holds the eight int16 digits
+// e_{8o..8o+7, j} of proof p (noct = ceil(nbases / 8); bases beyond nbases get zero digits).  nwin = msm_windows(c).
 struct MsmRecodeArgs {
     const fe* scalars; const uint32_t* rows;   // [row][batch]; scalar row per base (nullptr: row k)
     int mont;                                  // 1: Montgomery residues of wire values (sign-normalised before recoding), 0: canonical integers < r
@@ -125,30 +99,74 @@ struct MsmRecodeArgs {
 };
 void launch_msm_recode(const MsmRecodeArgs& a, hipStream_t s);
 // Number of windows for c-bit signed digits of scalars below r (the top window must absorb the last carry without overflow:
-// floor((r-1) / 2^(c (nwin-1))) + 1 <= 2^(c-1) - 1).  r < 2^254, top bits 0x30644e72e131a029...
+// floor((r-1) / 2^(c (nwin-1))) + 1 <= 2^(c-1) - 1).
 inline int msm_windows(int c) {
     int nwin = (254 + c - 1) / c;
     const int top_bits = 254 - c * (nwin - 1);                 // bits of r in the top window (1 .. c)
-    // value of r's top window: r >> (254 - top_bits), with r = 0x30644e72e131a029b85045b6... * 2^(254-64) (leading 64 bits are enough for c <= 32)
     const unsigned long long lead = 0xc19139cb84c680a6ull;      // floor(r / 2^190): the 64 leading bits of r counted from bit 253
     const unsigned long long top = lead >> (64 - top_bits);
     if (top + 1 > (1ull << (c - 1)) - 1) nwin++;
     return nwin;
 }
-// partial[(slice * nwin + j) * batch + p] = sum over the bases k of the slice of sign(e_kj) * table[k][|e_kj| - 1]
+// partial[(slice * nwin + j) * batch + p] = sum over the bases k of the slice of sign(e_kj) * T_k[|e_kj| - 1]
+// One wave per (slice of `per` consecutive bases, window j, 64 proofs).
 struct MsmWinArgs {
     const void* table; int c, nwin; size_t nbases;
     const uint4* digits; size_t batch;
-    size_t nslices, per;           // slices of `per` consecutive bases (per a multiple of 8)
+    size_t nslices, per;           // per: a multiple of 8
     void* partial;                 // G1Xyzz / G2Xyzz [nslices][nwin][batch]
     int placement;                 // workgroup -> (slice, window, proofs) map: 0 one XCD per slice, 1 four XCDs per slice (speed only)
     int exp_same_entry;            // MEASUREMENT ONLY (GSC_MSM_EXP=1 with test hooks on): every gather reads entry 0 — wrong sums, pure VALU time
 };
 void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s);
 void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s);
-// out[p] = sum_j 2^(c j) S[j * batch + p]
-void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, G1Xyzz* out, hipStream_t s);
-void launch_msm_horner_g2(const G2Xyzz* S, int nwin, int c, size_t batch, G2Xyzz* out, hipStream_t s);
+// out[p] = sum_j 2^(c j) S[j * batch + p] (+ addend[p] when addend != nullptr)
+void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, const G1Xyzz* addend, G1Xyzz* out, hipStream_t s);
+void launch_msm_horner_g2(const G2Xyzz* S, int nwin, int c, size_t batch, const G2Xyzz* addend, G2Xyzz* out, hipStream_t s);
+
+// Flat sets.  digits[o * batch + p] = eight int16 values of octet o for proof p (k_recode_flat):
+//   bit groups  the first nbit bases (a multiple of 8) are predicted to carry scalars in {-1, 0, 1} and are taken eight at a time:
+//               group o has a table of signed subset sums sub[o][v - 1] = sum_i t_i * base_{8o+i} for the balanced-ternary value
+//               v = sum_i t_i 3^i > 0 (MSM_GROUP_ENTRIES affine entries; v < 0 is the negated entry).  The prediction is checked for
+//               every wave of 64 proofs: gok[o * (batch/64) + wave] = 1 and slot 0 carries v, or 0 and the octet holds ordinary values.
+//               group_ok[o] = 0 disables a group for good (its subset sums hit the point at infinity);
+//   ordinary    slot i = the sign-normalised scalar of base 8o + i if it fits 15 bits, else MSM_FLAT_ESCAPE;
+//   window      octwin[o] >= 0: slots = digits octwin[o] .. +7 (c bits, c <= 15) of the single scalar rows[8 o]; the bases of such an
+//               octet are the points 2^(c j) P of one wide wire.
+// A value beyond its row (a wrong prediction) or an escape is multiplied out from the row's first entry: results never depend on
+// rowlen or on the grouping.
+constexpr uint32_t MSM_GROUP_ENTRIES = 3280;      // (3^8 - 1) / 2
+constexpr int32_t MSM_FLAT_ESCAPE = -32768;
+void launch_build_subset_g1(const G1Aff* bases, size_t ngroups, G1Aff* table, G1Xyzz* scratch, uint8_t* ok, hipStream_t s);
+void launch_build_subset_g2(const G2Aff* bases, size_t ngroups, G2Aff* table, G2Xyzz* scratch, uint8_t* ok, hipStream_t s);
+struct MsmFlatRecodeArgs {
+    const fe* scalars; const uint32_t* rows; const int32_t* octwin;   // Montgomery wire values [row][batch]; row per base; per octet first window or -1 (nullptr: none)
+    size_t nbases, batch; int c;
+    uint4* digits;
+    size_t nbit; const uint8_t* group_ok; uint8_t* gok;
+};
+void launch_msm_recode_flat(const MsmFlatRecodeArgs& a, hipStream_t s);
+// partial[slice * batch + p]; one wave per (slice of `per` consecutive bases, 64 proofs); per a multiple of 8, at most 512
+struct MsmFlatArgs {
+    const void* table; const uint64_t* rowoff; const uint32_t* rowlen; size_t nbases;
+    const uint4* digits; size_t batch;
+    size_t nslices, per;
+    void* partial;
+    size_t nbit; const void* sub; const uint8_t* gok;
+    const fe* scalars; const uint32_t* rows;          // for escapes
+};
+void launch_msm_flat_g1(const MsmFlatArgs& a, hipStream_t s);
+void launch_msm_flat_g2(const MsmFlatArgs& a, hipStream_t s);
+
+// One reduction level over slices: out[g][column] = sum of the partials of group g of slices; returns the number of groups (1 = out
+// is the final sum).  `batch` counts independent columns (proofs, or windows x proofs).  Groups hold 64 slices (butterfly over
+// lanes, small batches) or MSM_REDUCE_FANIN (lanes = columns, large batches), so `out` must have room for
+// ceil(nslices / MSM_REDUCE_FANIN) * batch points; it must not alias `partial`.
+constexpr size_t MSM_REDUCE_FANIN = 32;
+inline bool msm_reduce_by_proof(size_t nslices, size_t batch) { return (batch / 64) * ((nslices + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN) >= 128; }   // by-proof does 8x less work; the butterfly only wins when there are too few (proof group, chunk) waves
+inline size_t msm_reduce_groups(size_t nslices, size_t batch) { const size_t f = msm_reduce_by_proof(nslices, batch) ? MSM_REDUCE_FANIN : 64; return (nslices + f - 1) / f; }
+size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
+size_t launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
 
 // Commitment helpers (AES-V2).  points: batch XYZZ sums -> out: batch x 64 B big-endian canonical X|Y
 // (gnark's uncompressed G1 encoding, the prefix of the commitment hash); flags[proof] |= bit if the point is infinity.

@@ -69,7 +69,7 @@ def test_colliding_bases_agree_with_the_oracle(oracle, bit_groups):
     path = os.path.join(ROOT, "build", "pk.chacha20.colliding")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     open(path, "wb").write(pk_bytes)
-    env = dict(os.environ, GSC_MAX_BATCH="128", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_WIDE_TABLE_GB="4", GSC_BIT_GROUPS=bit_groups)
+    env = dict(os.environ, GSC_MAX_BATCH="128", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_BIT_GROUPS=bit_groups)
     out = subprocess.run([sys.executable, "-c", _SCRIPT, ROOT, path], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [l.split() for l in out.stdout.splitlines() if l.startswith("PROOF")]

@@ -208,7 +208,8 @@ def _digest(env_extra, algo=0, pk_path=None):
     import subprocess, sys
     from conftest import ROOT
     # small tables: these child processes share the device with the algorithms the test session already holds (~170 GB)
-    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_WIDE_TABLE_GB="4", **env_extra)
+    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8")
+    env.update(env_extra)
     args = [sys.executable, "-c", _OPTIONS_SCRIPT, ROOT, str(algo)] + ([pk_path] if pk_path else [])
     out = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -217,10 +218,12 @@ def _digest(env_extra, algo=0, pk_path=None):
 
 def test_engine_options_do_not_change_the_proofs():
     # Options are read at InitAlgorithm, so each configuration gets its own process (one at a time on the GPU).  GSC_BIT_GROUPS=0
-    # never uses the subset-sum tables, =2 predicts EVERY wire to be a bit, so every group holding a wider value takes the
-    # in-kernel fallback; the default predicts from a calibration witness.  All must give byte-identical proofs.
+    # predicts nothing: no subset-sum tables, every wire through the windowed kernel; =2 predicts EVERY wire to be a bit, so every
+    # group holding a wider value fails its check and its wide scalars take the flat kernel's escape (double-and-add from the
+    # scalar itself); GSC_ROW_MARGIN_BITS=-6 gives the narrow wires rows shorter than their values (multiplied out from the row's
+    # first entry); the default predicts from a calibration witness.  All must give byte-identical proofs.
     base = _digest({})
-    for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}):
+    for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_MSM_PLACEMENT": "1"}):
         assert _digest(extra) == base, extra
 
 
@@ -229,7 +232,7 @@ def test_engine_options_do_not_change_the_proofs_aes(aes_keys):
     pk_path = os.path.join(ROOT, "build", "keys", "pk.aes128")
     assert os.path.exists(pk_path)
     base = _digest({}, 1, pk_path)
-    for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}):
+    for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_ROW_MARGIN_BITS": "-6"}):
         assert _digest(extra, 1, pk_path) == base, extra
 
 
