@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
 ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
 
-EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw",
+EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw", "gsc_setup",
            "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_msm_z_kernel_ms", "gsc_debug_field_ops", "gsc_debug_compute_h"]
 
 
@@ -55,6 +55,8 @@ def lib():
         L.ProveBatch.argtypes = [GoSlice]
         L.gsc_prove_raw.restype = C.c_longlong
         L.gsc_prove_raw.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gsc_setup.restype = C.c_int
+        L.gsc_setup.argtypes = [GoSlice, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.gsc_set_deterministic_randomness.restype = C.c_int
         L.gsc_set_deterministic_randomness.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
         L.gsc_debug_prove.restype = C.c_longlong
@@ -107,6 +109,18 @@ def prove_batch(params_list) -> list:
     """ProveBatch (addition): list of dicts -> list of decoded JSON results."""
     s, keep = _slice(json.dumps(params_list).encode())
     return json.loads(_take(lib().ProveBatch(s)))
+
+
+def setup(r1cs: bytes, seed: bytes = None):
+    """gsc_setup: Groth16 Setup for an R1CS file -> (pk bytes, vk bytes) in gnark's layouts.  seed (32 bytes) makes TEST keys and
+    needs the test hooks; None = CSPRNG toxic waste."""
+    s, keep = _slice(r1cs)
+    pk, vk, npk, nvk = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+    if lib().gsc_setup(s, seed, C.byref(pk), C.byref(npk), C.byref(vk), C.byref(nvk)) != 0:
+        raise RuntimeError("gsc_setup failed (see stdout)")
+    out = C.string_at(pk.value, npk.value), C.string_at(vk.value, nvk.value)
+    lib().Free(pk); lib().Free(vk)
+    return out
 
 
 def prove_batch_bytes(params_json: bytes) -> bytes:

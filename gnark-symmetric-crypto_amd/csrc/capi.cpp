@@ -8,6 +8,7 @@
 #include "engine.hpp"
 #include "host_ciphers.hpp"
 #include "json.hpp"
+#include "setup.hpp"
 #include <sys/random.h>
 #include <cerrno>
 #include <condition_variable>
@@ -363,6 +364,21 @@ long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t
             if (!res[i].status) { memcpy(proofs + 196 * i, res[i].proof, res[i].proof_len); good++; }
         }
         return good;
+    } catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
+}
+
+int gsc_setup(GoSlice r1cs, const uint8_t* seed32, void** pk, size_t* pk_len, void** vk, size_t* vk_len) {
+    if (!pk || !pk_len || !vk || !vk_len) return -1;
+    *pk = *vk = nullptr; *pk_len = *vk_len = 0;
+    if (seed32 && hooks_refused("gsc_setup with a caller-supplied seed")) return -1;      // deterministic toxic waste: test keys only
+    try {
+        if (!r1cs.data || r1cs.len <= 0) throw std::runtime_error("error reading r1cs: EOF");
+        SetupKeys k = groth16_setup((const uint8_t*)r1cs.data, (size_t)r1cs.len, seed32, config_from_env().device);
+        void* a = malloc(k.pk.size()); void* b = malloc(k.vk.size());
+        if (!a || !b) { free(a); free(b); return -1; }
+        memcpy(a, k.pk.data(), k.pk.size()); memcpy(b, k.vk.data(), k.vk.size());
+        *pk = a; *pk_len = k.pk.size(); *vk = b; *vk_len = k.vk.size();
+        return 0;
     } catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
 }
 

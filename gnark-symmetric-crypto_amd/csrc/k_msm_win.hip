@@ -403,8 +403,49 @@ __global__ __launch_bounds__(64) void k_build_rows(const Aff<OldF>* bases, const
     }
 }
 
+// ---- Groth16 Setup: many independent multiples of ONE fixed point (the group generator) ----------------------------------------
+// out[i] = s_i * G from the window rows table[j][d-1] = d * 2^(c j) * G (built like any other rows from the bases 2^(c j) G).
+// Lanes are scalars.  Output: affine coordinates as canonical integers (8 little-endian 32-bit words per Fp element; G2: a0 then
+// a1), inf[i] = 1 for the point at infinity (zero scalar).
+__device__ __forceinline__ void store_canon_words(fe* dst, const fe9& mont) { store_fe(dst, Fp29::pack(Fp29::from_mont(mont))); }
+__device__ __forceinline__ void store_aff_canon(fe* dst, const Aff9<Fp29f>& a) { store_canon_words(dst, a.x); store_canon_words(dst + 1, a.y); }
+__device__ __forceinline__ void store_aff_canon(fe* dst, const Aff9<Fp2x>& a) {
+    store_canon_words(dst, a.x.a0); store_canon_words(dst + 1, a.x.a1); store_canon_words(dst + 2, a.y.a0); store_canon_words(dst + 3, a.y.a1);
+}
+template <class F>
+__global__ __launch_bounds__(64) void k_fixed_mul(const fe* table, int c, int nwin, const fe* scalars, size_t n, fe* out, uint8_t* inf) {
+    using C = Curve9<F>;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe s = load_fe(scalars + i);
+    const uint32_t cmask = (1u << c) - 1, D = 1u << (c - 1);
+    uint32_t carry = 0;
+    Xyzz9<F> acc = C::infinity();
+    for (int j = 0; j < nwin; j++) {
+        uint32_t raw = (s.l[0] & cmask) + carry;
+#pragma unroll
+        for (int q = 0; q < 7; q++) s.l[q] = __builtin_amdgcn_alignbit(s.l[q + 1], s.l[q], c);
+        s.l[7] >>= c;
+        int32_t d = (int32_t)raw;
+        if (raw >= D) { d -= (int32_t)(1u << c); carry = 1; } else carry = 0;
+        if (d) {
+            const int32_t mag = d < 0 ? -d : d;
+            acc = C::template madd<true>(acc, unpack_aff(load_raw<F>(table + ((size_t)j * D + (size_t)(mag - 1)) * (2 * F::WORDS)), d < 0));
+        }
+    }
+    fe* o = out + i * (2 * F::WORDS);
+    if (acc.inf) { inf[i] = 1; for (int q = 0; q < 2 * F::WORDS; q++) store_fe(o + q, fe{}); }
+    else { inf[i] = 0; store_aff_canon(o, C::to_aff(acc)); }
+}
+
 }  // namespace
 
+void launch_fixed_mul_g1(const G1Aff* table, int c, int nwin, const fe* scalars, size_t n, fe* out, uint8_t* inf, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_fixed_mul<Fp29f>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, reinterpret_cast<const fe*>(table), c, nwin, scalars, n, out, inf);
+}
+void launch_fixed_mul_g2(const G2Aff* table, int c, int nwin, const fe* scalars, size_t n, fe* out, uint8_t* inf, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_fixed_mul<Fp2x>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, reinterpret_cast<const fe*>(table), c, nwin, scalars, n, out, inf);
+}
 void launch_msm_recode(const MsmRecodeArgs& a, hipStream_t s) {
     if (!a.nbases) return;
     const dim3 grid((unsigned)(a.batch / 64), (unsigned)((a.nbases + 7) / 8));

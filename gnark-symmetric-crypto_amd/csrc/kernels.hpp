@@ -168,6 +168,12 @@ inline size_t msm_reduce_groups(size_t nslices, size_t batch) { const size_t f =
 size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
 size_t launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
 
+// Groth16 Setup: out[i] = scalars[i] * G for n independent canonical scalars (8 little-endian words each), from the window rows
+// table[j * D + d - 1] = d * 2^(c j) * G, D = 2^(c-1), nwin = msm_windows(c).  out: affine coordinates as canonical integers
+// (G1: x, y = 2 x 32 B; G2: x.a0, x.a1, y.a0, y.a1 = 4 x 32 B); inf[i] = 1 for a zero scalar.
+void launch_fixed_mul_g1(const G1Aff* table, int c, int nwin, const fe* scalars, size_t n, fe* out, uint8_t* inf, hipStream_t s);
+void launch_fixed_mul_g2(const G2Aff* table, int c, int nwin, const fe* scalars, size_t n, fe* out, uint8_t* inf, hipStream_t s);
+
 // Commitment helpers (AES-V2).  points: batch XYZZ sums -> out: batch x 64 B big-endian canonical X|Y
 // (gnark's uncompressed G1 encoding, the prefix of the commitment hash); flags[proof] |= bit if the point is infinity.
 void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s);

@@ -4,10 +4,11 @@
 // The reference's verifier is a CPU-side component (three pairings per proof), and so is this one:
 // it is NOT part of the GPU hot path and the prover never calls it.  Groth16 verification over BN254 with gnark's
 // key / proof encodings and gnark's commitment extension for the AES circuits (App. H).
-// Everything numeric is self-contained in this file (4 x 64-bit Montgomery arithmetic, Fp2/Fp12 towers, optimal-ate
+// Everything numeric is host code (host_field.hpp: 4 x 64-bit Montgomery arithmetic; here: Fp2/Fp12 towers, optimal-ate
 // pairing); JSON, base64 and SHA-256 come from the same host sources as libprove.
 #include "../../include/libverify.h"
 #include "host_ciphers.hpp"
+#include "host_field.hpp"
 #include "json.hpp"
 #include <array>
 #include <cstdio>
@@ -23,82 +24,8 @@
 
 namespace {
 
-using u64 = uint64_t;
-using u128 = unsigned __int128;
+using namespace gsc::hostf;
 
-struct U256 { u64 w[4]; };
-inline bool geq(const U256& a, const U256& b) { for (int i = 3; i >= 0; i--) { if (a.w[i] != b.w[i]) return a.w[i] > b.w[i]; } return true; }
-inline u64 sub_into(U256& a, const U256& b) { u64 br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a.w[i] - b.w[i] - br; a.w[i] = (u64)d; br = (u64)(d >> 64) & 1; } return br; }
-inline u64 add_into(U256& a, const U256& b) { u64 c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)a.w[i] + b.w[i] + c; a.w[i] = (u64)s; c = (u64)(s >> 64); } return c; }
-
-// prime field with Montgomery representation; Tag selects the modulus
-template <int Tag>
-struct Fe {
-    U256 v;   // Montgomery form
-    static const U256 MOD; static U256 R1, R2; static u64 NINV; static bool ready;
-    static void init() {
-        if (ready) return;
-        u64 inv = 1; for (int i = 0; i < 6; i++) inv *= 2 - MOD.w[0] * inv;
-        NINV = 0 - inv;
-        U256 t{{1, 0, 0, 0}};
-        for (int i = 0; i < 512; i++) {
-            u64 top = t.w[3] >> 63;
-            for (int k = 3; k > 0; k--) t.w[k] = (t.w[k] << 1) | (t.w[k - 1] >> 63);
-            t.w[0] <<= 1;
-            if (top || geq(t, MOD)) sub_into(t, MOD);
-            if (i == 255) R1 = t;
-        }
-        R2 = t; ready = true;
-    }
-    static Fe zero() { return Fe{{{0, 0, 0, 0}}}; }
-    static Fe one() { return Fe{R1}; }
-    static Fe from_u64(u64 x) { Fe a{{{x, 0, 0, 0}}}; return a * Fe{R2}; }
-    bool is_zero() const { return (v.w[0] | v.w[1] | v.w[2] | v.w[3]) == 0; }
-    bool operator==(const Fe& o) const { return !memcmp(v.w, o.v.w, 32); }
-    Fe operator+(const Fe& o) const { Fe r = *this; add_into(r.v, o.v); if (geq(r.v, MOD)) sub_into(r.v, MOD); return r; }
-    Fe operator-(const Fe& o) const { Fe r = *this; if (sub_into(r.v, o.v)) add_into(r.v, MOD); return r; }
-    Fe neg() const { return is_zero() ? *this : Fe{MOD} - *this; }
-    Fe operator*(const Fe& o) const {
-        u64 t[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 4; i++) {
-            u128 c = 0;
-            for (int j = 0; j < 4; j++) { c += (u128)v.w[j] * o.v.w[i] + t[j]; t[j] = (u64)c; c >>= 64; }
-            c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
-            const u64 m = t[0] * NINV;
-            c = (u128)m * MOD.w[0] + t[0]; c >>= 64;
-            for (int j = 1; j < 4; j++) { c += (u128)m * MOD.w[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
-            c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
-        }
-        Fe r{{{t[0], t[1], t[2], t[3]}}};
-        if (t[4] || geq(r.v, MOD)) sub_into(r.v, MOD);
-        return r;
-    }
-    Fe sq() const { return *this * *this; }
-    Fe pow(const u64* e, int limbs) const {
-        Fe acc = one();
-        for (int i = limbs * 64 - 1; i >= 0; i--) { acc = acc.sq(); if ((e[i / 64] >> (i % 64)) & 1) acc = acc * *this; }
-        return acc;
-    }
-    Fe inv() const { U256 e = MOD; e.w[0] -= 2; return pow(e.w, 4); }
-    U256 canon() const { Fe o{{{1, 0, 0, 0}}}; return (*this * o).v; }
-    static bool from_be(const uint8_t* b, Fe& out) {
-        U256 c; for (int i = 0; i < 4; i++) { u64 x = 0; for (int k = 0; k < 8; k++) x = (x << 8) | b[(3 - i) * 8 + k]; c.w[i] = x; }
-        if (geq(c, MOD)) return false;
-        out = Fe{c} * Fe{R2}; return true;
-    }
-    void to_be(uint8_t* b) const { U256 c = canon(); for (int i = 0; i < 4; i++) for (int k = 0; k < 8; k++) b[(3 - i) * 8 + k] = (uint8_t)(c.w[i] >> (56 - 8 * k)); }
-    bool lex_large() const {     // canonical value > (MOD-1)/2
-        U256 c = canon(), h = MOD; h.w[0] -= 1;
-        for (int i = 0; i < 4; i++) h.w[i] = (h.w[i] >> 1) | (i < 3 ? h.w[i + 1] << 63 : 0);
-        for (int i = 3; i >= 0; i--) if (c.w[i] != h.w[i]) return c.w[i] > h.w[i];
-        return false;
-    }
-};
-template <int T> U256 Fe<T>::R1; template <int T> U256 Fe<T>::R2; template <int T> u64 Fe<T>::NINV; template <int T> bool Fe<T>::ready = false;
-template <> const U256 Fe<0>::MOD = {{0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull}};   // p
-template <> const U256 Fe<1>::MOD = {{0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull}};   // r
-using Fp = Fe<0>;
-using Fr = Fe<1>;
 
 struct Fp2 {
     Fp a, b;   // a + b u, u^2 = -1

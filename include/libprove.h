@@ -51,6 +51,14 @@ extern struct Prove_return ProveBatch(GoSlice params);
  * ciphertexts: n x 64 bytes.  Returns the number of proofs produced, or -1 if the algorithm is not initialised. */
 extern long long gsc_prove_raw(GoUint8 cipher, const uint8_t *inputs, size_t n, uint8_t *proofs, uint32_t *proof_lens, uint8_t *ciphertexts);
 
+/* Groth16 Setup for one of the reference's circuits (stands in for groth16.Setup, keygen.go:345,384,423; needed because the
+ * reference ships no pk.aes128 / pk.aes256).  r1cs: the gnark v0.11.0 constraint system file.  On success (0) *pk / *vk are malloc'd
+ * buffers in groth16.ProvingKey.WriteTo / VerifyingKey.WriteTo layout (what InitAlgorithm and the verifier read); release both
+ * with Free.  The group elements are computed on the GPU.  seed32 == NULL: toxic waste from the OS CSPRNG, discarded before the
+ * call returns.  A non-NULL 32-byte seed makes the keys a deterministic function of (r1cs, seed) — TEST keys — and is refused (-1)
+ * unless test hooks are enabled (below). */
+extern int gsc_setup(GoSlice r1cs, const uint8_t *seed32, void **pk, size_t *pk_len, void **vk, size_t *vk_len);
+
 /* TEST HOOKS.  gsc_set_deterministic_randomness and every gsc_debug_* function below refuse to work (return -1, message on
  * stdout) unless the process was started with GSC_ENABLE_TEST_HOOKS=1 in its environment; the variable is read once, when the
  * library is loaded.  A production host never sets it: fixed prover randomness voids zero-knowledge for the whole process. */
