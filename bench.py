@@ -38,7 +38,7 @@ ALGOS = {"chacha20": (0, "chacha20", 32), "aes128": (1, "aes-128-ctr", 16), "aes
 # algorithmic bytes per proof — whole path, and the MSM stage alone (AES: the survey's upper bounds)
 BYTES_PER_PROOF = {"chacha20": 28_281_728, "aes128": 115_002_752, "aes256": 129_366_656}
 MSM_BYTES_PER_PROOF = {"chacha20": 10_589_440, "aes128": 46_750_944, "aes256": 57_991_904}
-SETUP_SEEDS = {"aes128": bytes([1] * 32), "aes256": bytes([2] * 32)}      # the reference ships no pk.aes*: keys come from the product's own Setup
+SETUP_SEEDS = {"aes128": bytes([1] * 32), "aes256": bytes([2] * 32)}      # CPU-baseline keys (oracle Setup; any valid key costs the same to prove with)
 
 
 def golden(name):
@@ -257,7 +257,7 @@ def main():
             if name == "chacha20":
                 pk = golden("pk.chacha20")
             else:
-                pk, _vk = g.setup(r1cs, SETUP_SEEDS[name])          # the product's own Groth16 Setup (GPU); deterministic in the seed
+                pk, _vk = g.setup(r1cs)                              # the product's own Groth16 Setup (GPU), CSPRNG toxic waste
             if not g.init_algorithm(algo, pk, r1cs):
                 raise SystemExit("InitAlgorithm failed for " + name)
 
