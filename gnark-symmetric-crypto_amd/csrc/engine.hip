@@ -66,6 +66,9 @@ struct MsmSet {                     // one fixed-base MSM of the proving key (ke
 EngineConfig config_from_env() {
     EngineConfig c;
     c.device = env_int("GSC_DEVICE", 0);
+    if (const char* dv = getenv("GSC_DEVICES")) {      // "0,1,2,3": one engine replica per listed device, batches split over them
+        for (const char* q = dv; *q;) { while (*q == ',' || *q == ' ') q++; if (!*q) break; char* end = nullptr; const long v = strtol(q, &end, 10); if (end == q) throw std::runtime_error("GSC_DEVICES: expected a comma-separated list of device ordinals"); c.devices.push_back((int)v); q = end; }
+    }
     c.max_batch = (size_t)env_int("GSC_MAX_BATCH", 1024);
     c.lanes = env_int("GSC_LANES", 1);
     c.min_split = (size_t)env_int("GSC_MIN_SPLIT", 256);
@@ -649,25 +652,43 @@ void debug_field_ops(int device, int field, int op, const uint8_t* a, const uint
     HIP_CHECK(hipMemcpy(out, dout.p, 32 * n, hipMemcpyDeviceToHost));
 }
 
-Algorithm::Algorithm(Cipher cipher, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cfg)
-    : impl_(new AlgorithmImpl(cipher, pk, pk_len, r1cs, r1cs_len, cfg)) {}
+// ---- Algorithm: one replica of the engine per device (GSC_DEVICES), batches split over the replicas ----
+Algorithm::Algorithm(Cipher cipher, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cfg) {
+    std::vector<int> devs = cfg.devices.empty() ? std::vector<int>{cfg.device} : cfg.devices;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the GPU prover has no CPU fallback");
+    for (int d : devs) if (d < 0 || d >= ndev) throw std::runtime_error("GSC_DEVICES / GSC_DEVICE: device " + std::to_string(d) + " does not exist (" + std::to_string(ndev) + " visible)");
+    impls_.resize(devs.size());
+    // every replica decodes the key and builds its own tables on its device; the builds run side by side
+    std::exception_ptr err; std::mutex err_mu; std::vector<std::thread> th;
+    auto make = [&](size_t i) {
+        try { EngineConfig c = cfg; c.device = devs[i]; impls_[i].reset(new AlgorithmImpl(cipher, pk, pk_len, r1cs, r1cs_len, c)); }
+        catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+    };
+    for (size_t i = 1; i < devs.size(); i++) th.emplace_back(make, i);
+    make(0);
+    for (auto& t : th) t.join();
+    if (err) { impls_.clear(); std::rethrow_exception(err); }
+}
 Algorithm::~Algorithm() = default;
-Cipher Algorithm::cipher() const { return impl_->cipher; }
-size_t Algorithm::max_batch() const { return impl_->cap; }
-void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impl_->lanes[0]->stage_ms[i]; }
-float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impl_->lanes[0]->last_batch; if (nbases) *nbases = impl_->mZ.nwide; return impl_->lanes[0]->msm_z_kernel_ms; }
+Cipher Algorithm::cipher() const { return impls_[0]->cipher; }
+size_t Algorithm::max_batch() const { size_t c = 0; for (auto& i : impls_) c += i->cap; return c; }
+size_t Algorithm::devices() const { return impls_.size(); }
+void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impls_[0]->lanes[0]->stage_ms[i]; }
+float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impls_[0]->lanes[0]->last_batch; if (nbases) *nbases = impls_[0]->mZ.nwide; return impls_[0]->lanes[0]->msm_z_kernel_ms; }
 std::string Algorithm::describe() const {
-    char buf[512];
-    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu grouped A=%zu B=%zu K=%zu wide(windowed+expanded) A=%zu+%zu B=%zu+%zu K=%zu+%zu",
-             impl_->n_wires, impl_->n_constraints, impl_->L, impl_->cap, impl_->lanes.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
+    const AlgorithmImpl* impl_ = impls_[0].get();
+    char buf[640];
+    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu devices=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu grouped A=%zu B=%zu K=%zu wide(windowed+expanded) A=%zu+%zu B=%zu+%zu K=%zu+%zu",
+             impl_->n_wires, impl_->n_constraints, impl_->L, max_batch(), impl_->lanes.size(), impls_.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
              impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases, impl_->mA.nbit, impl_->mB1.nbit, impl_->mK.nbit,
              impl_->mA.nwide, impl_->mA.nexpanded, impl_->mB1.nwide, impl_->mB1.nexpanded, impl_->mK.nwide, impl_->mK.nexpanded);
     return buf;
 }
-size_t Algorithm::domain_size() const { return impl_->domain_n; }
+size_t Algorithm::domain_size() const { return impls_[0]->domain_n; }
 void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out) {
-    std::lock_guard<std::mutex> lock(impl_->mu);
-    AlgorithmImpl& a = *impl_;
+    std::lock_guard<std::mutex> lock(impls_[0]->mu);
+    AlgorithmImpl& a = *impls_[0];
     if (m > a.n_constraints) throw std::runtime_error("debug_compute_h: more rows than constraints");
     HIP_CHECK(hipSetDevice(a.cfg.device));
     AlgorithmImpl::Lane& ln = *a.lanes[0];
@@ -682,12 +703,11 @@ void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out)
     HIP_CHECK(hipMemcpyAsync(h_out, ln.d_A.p, a.domain_n * B * 32, hipMemcpyDeviceToHost, ln.stream));
     HIP_CHECK(hipStreamSynchronize(ln.stream));
 }
-void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
-    std::lock_guard<std::mutex> lock(impl_->mu);
-    AlgorithmImpl& a = *impl_;
+// one replica: cut the request list into chunks (multiples of 64 proofs, at most one lane's capacity, at least two chunks per call
+// when there are two lanes and enough work) and let every lane pull chunks until none are left
+static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
+    std::lock_guard<std::mutex> lock(a.mu);
     if (!n) return;
-    // cut the request list into chunks (multiples of 64 proofs, at most one lane's capacity, at least two chunks per call when
-    // there are two lanes and enough work) and let every lane pull chunks until none are left
     const size_t nl = a.lanes.size(), lane_cap = a.lanes[0]->cap;
     size_t nchunks = (n + lane_cap - 1) / lane_cap;
     if (nl > 1 && n >= 2 * a.cfg.min_split) { const size_t want = (nchunks + nl - 1) / nl * nl; nchunks = want; }
@@ -710,6 +730,25 @@ void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* res
     const size_t nthreads = nchunks < nl ? nchunks : nl;
     std::vector<std::thread> th;
     for (size_t li = 1; li < nthreads; li++) th.emplace_back(work, li);
+    work(0);
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
+    if (!n) return;
+    const size_t nd = impls_.size();
+    if (nd == 1 || n <= 64) return prove_on_replica(*impls_[0], reqs, n, results, debug_first);
+    // Proofs are independent: contiguous shares (multiples of 64) go to the replicas, one host thread per device; nothing is
+    // exchanged between devices (the "gather" is the results array the threads fill).
+    size_t share = ((n + nd - 1) / nd + 63) / 64 * 64;
+    std::exception_ptr err; std::mutex err_mu; std::vector<std::thread> th;
+    auto work = [&](size_t d) {
+        const size_t off = d * share;
+        if (off >= n) return;
+        try { prove_on_replica(*impls_[d], reqs + off, n - off < share ? n - off : share, results + off, d == 0 ? debug_first : nullptr); }
+        catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+    };
+    for (size_t d = 1; d < nd; d++) th.emplace_back(work, d);
     work(0);
     for (auto& t : th) t.join();
     if (err) std::rethrow_exception(err);

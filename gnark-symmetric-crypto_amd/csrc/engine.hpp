@@ -27,7 +27,9 @@ struct ProofResult {
 };
 
 struct EngineConfig {
-    int device = 0;
+    int device = 0;              // GSC_DEVICE: the device of a single-replica engine
+    std::vector<int> devices;    // GSC_DEVICES=0,1,...: one replica (key tables, batch buffers, host thread) per listed device; every batch is
+                                 // split over them in contiguous shares — a single FFI host process drives all the GPUs of a node
     size_t max_batch = 1024;     // proofs in flight over all lanes (rounded to a multiple of 64 per lane)
     int lanes = 1;               // concurrent HIP streams, each with its own batch buffers (GSC_LANES)
     size_t min_split = 256;      // a call with at least 2*min_split proofs is spread over the lanes (GSC_MIN_SPLIT)
@@ -52,7 +54,8 @@ class Algorithm {
     Cipher cipher() const;
     // proves n independent statements; results[i] corresponds to reqs[i].  Thread-safe (serialised per algorithm).
     void prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first = nullptr);
-    size_t max_batch() const;
+    size_t max_batch() const;      // over all devices
+    size_t devices() const;
     std::string describe() const;    // sizes, table memory — for logs / DESIGN numbers
     // raw timing of the last prove_batch, milliseconds per stage (solve, ntt, msm, finalize), device events
     void last_stage_ms(float out[4]) const;
@@ -65,7 +68,7 @@ class Algorithm {
     void debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out);
     size_t domain_size() const;
   private:
-    std::unique_ptr<AlgorithmImpl> impl_;
+    std::vector<std::unique_ptr<AlgorithmImpl>> impls_;      // one per device
 };
 
 // TEST HOOK: runs element-wise operations of the device's radix-2^29 field implementation (see kernels.hpp launch_field_ops).

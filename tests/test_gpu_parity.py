@@ -193,6 +193,7 @@ pk = open(sys.argv[3], "rb").read() if len(sys.argv) > 3 else golden("pk.chacha2
 r1cs = golden(["r1cs.chacha20", "r1cs.aes128", "r1cs.aes256"][algo])
 assert g.init_algorithm(algo, pk, r1cs)
 assert "lanes=%s " % os.environ.get("GSC_LANES", "1") in g.describe(algo), g.describe(algo)
+assert "devices=%d " % len(os.environ.get("GSC_DEVICES", "0").split(",")) in g.describe(algo), g.describe(algo)
 rnd = random.Random(4242)
 n = 333 if algo == 0 else 70
 keylen = 16 if algo == 1 else 32
@@ -223,7 +224,9 @@ def test_engine_options_do_not_change_the_proofs():
     # scalar itself); GSC_ROW_MARGIN_BITS=-6 gives the narrow wires rows shorter than their values (multiplied out from the row's
     # first entry); the default predicts from a calibration witness.  All must give byte-identical proofs.
     base = _digest({})
-    for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_MSM_PLACEMENT": "1"}):
+    # GSC_DEVICES=0,0: two engine replicas (here both on the one device of the box), every batch split between them — the in-library
+    # multi-GPU path of a single FFI host process.
+    for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_MSM_PLACEMENT": "1"}, {"GSC_DEVICES": "0,0"}):
         assert _digest(extra) == base, extra
 
 
