@@ -99,7 +99,7 @@ class AlgorithmImpl {
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
     uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; std::vector<uint32_t> level_long; int has_div = 0;
     // NTT
-    DevBuf<int32_t> tw_fwd, tw_inv, qr; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, den_inv
+    DevBuf<int32_t> tw_fwd, tw_inv, qr; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n
     // MSM sets
     MsmSet<G1Aff> mA, mB1, mK, mZ, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
     // batch buffers: one set per lane.  A lane = a HIP stream with its own witness / polynomial / partial-sum buffers; with more than
@@ -382,9 +382,13 @@ class AlgorithmImpl {
             dom.alloc(6);
             launch_fr_from_be(d_be.p, dom.p, 5, stream);
             tw_fwd.alloc(domain_n / 2 * 12); tw_inv.alloc(domain_n / 2 * 12); scale_mid.alloc(domain_n); scale_out.alloc(domain_n); qr.alloc((2 * NTT_QMAX + 1) * 12);
-            launch_ntt_constants(dom.p, dom.p + 1, dom.p + 2, dom.p + 3, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, stream);
+            DevBuf<uint32_t> d_flag(1); uint32_t flag = 0;
+            HIP_CHECK(hipMemsetAsync(d_flag.p, 0, 4, stream));
+            launch_ntt_constants(dom.p, dom.p + 1, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, d_flag.p, stream);
             HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
+            if (flag) throw std::runtime_error("pk: the domain generator is not gnark-crypto's root of unity for this size");
         }
         auto cat = [](std::vector<uint8_t> a, std::initializer_list<const std::vector<uint8_t>*> more) { for (auto* m : more) a.insert(a.end(), m->begin(), m->end()); return a; };
         const uint32_t ROW_ONE = 0, ROW_R = (uint32_t)n_wires, ROW_S = ROW_R + 1, ROW_NRS = ROW_R + 2;

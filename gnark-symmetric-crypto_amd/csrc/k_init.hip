@@ -188,9 +188,14 @@ __device__ __forceinline__ fe fr_pow_u32(const fe& a, uint32_t e) {
 // kernels (bn254_fp29.hpp): twiddles and den_inv in its Montgomery domain (2^261); scale_mid additionally carries the factor
 // 2^261/2^256 that moves the solver's a/b/c values (2^256 domain) into that domain; scale_out is a plain integer so that the
 // last product of the pipeline leaves Montgomery form.
-__device__ __forceinline__ fe to_fr29_image(const fe& old_mont) { return Fr29::pack(Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(old_mont))))); }
-__global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
-                                int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, int32_t* qr) {
+// gnark-crypto's 2^28-th primitive root of unity of Fr, canonical, 8 little-endian words
+__device__ __forceinline__ fe fr_root_2_28() {
+    fe c; const uint32_t w[8] = {0x725b19f0u, 0x9bd61b6eu, 0x41112ed4u, 0x402d111eu, 0x8ef62abcu, 0x00e0a7ebu, 0xa58a7e85u, 0x2a3c09f0u};
+    for (int i = 0; i < 8; i++) c.l[i] = w[i];
+    return Fr::to_mont(c);
+}
+__global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* n_inv, int L,
+                                int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 1u << L;
     if (i <= 2 * NTT_QMAX) {      // q*r, q = i - NTT_QMAX, as tight limbs with a signed top limb: the NTT kernels' range reduction subtracts these
@@ -207,17 +212,20 @@ __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* 
         const fe9 b = Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(fr_pow_u32(*omega_inv, i)))));
         for (int k = 0; k < 12; k++) { tw_fwd[12 * (size_t)i + k] = k < 9 ? f.l[k] : 0; tw_inv[12 * (size_t)i + k] = k < 9 ? b.l[k] : 0; }
     }
+    fe zeta = fr_root_2_28();                       // -> the primitive 2n-th root: 27 - L squarings
+    for (int t = 0; t < 27 - L; t++) zeta = Fr::sqr(zeta);
+    const fe zeta_inv = Fr::mul(zeta, *omega_inv);                              // zeta^-1 = zeta * omega^-1 (zeta^2 = omega)
     uint32_t br = __brev(i) >> (32 - L);
     {
         fe9 c; for (int k = 0; k < 9; k++) c.l[k] = Fr29Q::FROM_R256(k);
-        const fe9 sm = Fr29::to_mont(Fr29::unpack(Fr::from_mont(Fr::mul(*n_inv, fr_pow_u32(*g, br)))));
+        const fe9 sm = Fr29::to_mont(Fr29::unpack(Fr::from_mont(Fr::mul(*n_inv, fr_pow_u32(zeta, br)))));
         scale_mid[i] = Fr29::pack(Fr29::freeze(Fr29::mul(sm, c)));
     }
-    scale_out[i] = Fr::from_mont(Fr::mul(*n_inv, fr_pow_u32(*g_inv, br)));
+    const fe half = Fr::inv(Fr::from_u32(2));
+    scale_out[i] = Fr::from_mont(Fr::mul(Fr::mul(*n_inv, half), fr_pow_u32(zeta_inv, br)));
     if (i == 0) {
-        fe gn = *g;
-        for (int t = 0; t < L; t++) gn = Fr::sqr(gn);
-        *den_inv = to_fr29_image(Fr::inv(Fr::sub(gn, Fr::one())));
+        *half_c = Fr::from_mont(Fr::mul(*n_inv, Fr::from_u32(16)));
+        if (!Fr::eq(Fr::sqr(zeta), *omega)) atomicOr(flag, 1u);
     }
 }
 
@@ -279,12 +287,12 @@ void launch_build_subset_g2(const G2Aff* bases, size_t ngroups, G2Aff* table, G2
     if (ngroups) hipLaunchKernelGGL((k_build_subset<Fp2x, Fp2>), dim3(blocks_for(ngroups, 64)), dim3(64), 0, s,
                                     reinterpret_cast<const Aff<Fp2>*>(bases), ngroups, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch), ok);
 }
-void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
-                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, int32_t* qr, hipStream_t s) {
+void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* n_inv, int L,
+                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag, hipStream_t s) {
     size_t n = (size_t)1 << L;
     if (n < 2 * NTT_QMAX + 1) n = 2 * NTT_QMAX + 1;
-    hipLaunchKernelGGL(k_ntt_constants, dim3(blocks_for(n, 64)), dim3(64), 0, s, omega, omega_inv, g, g_inv, n_inv, L,
-                       tw_fwd, tw_inv, scale_mid, scale_out, den_inv, qr);
+    hipLaunchKernelGGL(k_ntt_constants, dim3(blocks_for(n, 64)), dim3(64), 0, s, omega, omega_inv, n_inv, L,
+                       tw_fwd, tw_inv, scale_mid, scale_out, half_c, qr, flag);
 }
 
 }  // namespace gsc

@@ -1,18 +1,24 @@
 // Quotient polynomial H = (A*B - C) / (X^n - 1) over BN254 Fr, batched over proofs.
 //
 // Replaces computeH inside groth16.Prove (reference libraries/prover/impl/provers.go:148,216; gnark
-// backend/groth16/bn254.computeH + gnark-crypto fr/fft — SURVEY.md §8(a) a7, mathematics App. D):
-//   3 inverse NTTs (DIF, natural -> bit-reversed), coset scaling, 3 forward NTTs (DIT, bit-reversed -> natural),
-//   pointwise (a*b - c)/(g^n - 1), 1 inverse coset NTT (DIF) whose bit-reversed output order is exactly the
-//   order pk.G1.Z is stored in.
+// backend/groth16/bn254.computeH + gnark-crypto fr/fft — SURVEY.md §8(a) a7, mathematics App. D).  gnark evaluates A, B, C on a
+// coset, divides pointwise and interpolates back: seven transforms.  For a SATISFIED constraint system (c_i = a_i b_i on the
+// domain: what the solver has just checked — a proof is only released when it holds) six are enough and C is never multiplied:
+//   A B = P_lo + X^n P_hi,  H = P_hi  (deg A, B < n),      A B mod (X^n - 1) = P_lo + P_hi = S,      A B mod (X^n + 1) = P_lo - P_hi = D
+//   S = iNTT(c)  (c_i = a_i b_i are the values of A B on the n-th roots of unity),   D = the negacyclic product: values of A and B on
+//   zeta * (roots of unity), zeta^n = -1, multiplied pointwise and interpolated back;   H = (S - D) / 2.
+// The same polynomial, hence the same canonical coefficients, as gnark's (A B - C) / (X^n - 1).
+//   2 inverse NTTs (a, b: DIF, natural -> bit-reversed), scaling by zeta^j, 2 forward NTTs (DIT, bit-reversed -> natural),
+//   pointwise a*b, 1 inverse NTT + scaling by zeta^-j (D), 1 inverse NTT (c -> S); the bit-reversed output order of a DIF
+//   transform is exactly the order pk.G1.Z is stored in.
 //
 // Data stay in the solver's [index][proof] layout for the whole pipeline (no transposes).  n = 2^L is split
 // as 2^Lhi x 2^Llo: "strided" kernels own the stages that couple the top Lhi index bits (groups of 2^Lhi
 // elements at stride 2^Llo), "contiguous" kernels the low Llo bits.  Because DIF ends where DIT begins, the
-// seven transforms take four kernels:
-//   K1 strided DIF head (a,b,c) | K2 contiguous DIF tail + coset scale + DIT head (a,b,c)
-//   K3 strided DIT tail (a,b,c) + pointwise + strided DIF head (h) | K4 contiguous DIF tail + final scale (h).
-// Every kernel stages a tile of P proofs x 2^Lhi (or 2^Llo) elements in LDS, limb-major, one radix-2 stage
+// six transforms take four kernels:
+//   K1 strided DIF head (a,b,c) | K2 contiguous DIF tail + zeta scale + DIT head (a,b)
+//   K3 strided DIT tail (a,b) + pointwise + strided DIF head (d) | K4 contiguous DIF tails of c and d, h = (S - D) / 2.
+// Every kernel stages a tile of P proofs x 2^Lhi (or 2^Llo) elements in LDS, limb-major, two radix-2 stages
 // per barrier; global accesses are P*32 = 128-byte segments.
 #include "kernels.hpp"
 #include "bn254_fp29.hpp"
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
     }
 }
 
-// K2: contiguous DIF tail, coset scale, contiguous DIT head.  grid (2^Lhi, batch/P, nvec); block (2^(Llo-2) * P)
+// K2: contiguous DIF tail, scale by zeta^j / n (and into the 2^261 domain), contiguous DIT head.  grid (2^Lhi, batch/P, 2: a, b); block (2^(Llo-2) * P)
 __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
@@ -219,20 +225,19 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
     }
 }
 
-// K3: strided DIT tail for a, b, c; h = (a*b - c) * den_inv; strided DIF head for h (written over a).  The last DIT stage and the
+// K3: strided DIT tail for a and b; d = a*b on the zeta-coset; strided DIF head for d (written over a).  The last DIT stage and the
 // first DIF stage pair the same elements (e, e + G/2), so they stay in registers: each thread keeps two such pairs and folds
-// a, then b, then c into one running value per element (a, a*b, (a*b - c) * den_inv).
-__global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, const fe* vc, size_t batch) {
+// a, then b into one running value per element.
+__global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t G = 1u << Lhi;
     const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
     const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
     Tile t{smem, G * P};
-    const fe9 den = F::load(pl.den_inv);
     fe9 lo0, hi0, lo1, hi1;        // running values at elements (u4 + j*G/4) and (u4 + j*G/4 + G/2), j = 0, 1
-    for (int k = 0; k < 3; k++) {
-        const fe* vec = k == 0 ? va : k == 1 ? vb : vc;
+    for (int k = 0; k < 2; k++) {
+        const fe* vec = k == 0 ? va : vb;
         for (uint32_t e = u4; e < G; e += G / 4) {
             const size_t idx = ((size_t)e << Llo) + g;
             t.put(e, q, F::load(vec + idx * batch + q0 + q));
@@ -246,14 +251,13 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
             const fe9 v = mulw<false>(t.get(e2, q), pl.tw_fwd, ex, pl.qr);
             const fe9 x1 = F::norm(F::add(u, v)), x2 = F::norm(F::sub(u, v));      // tight; |value| <= 2^256/r + 8 * 1.1 < 15 r
             if (k == 0) { lo = x1; hi = x2; }
-            else if (k == 1) { lo = F::mul(lo, x1); hi = F::mul(hi, x2); }                                   // a*b in (-1.4r, 2.4r)
-            else { lo = F::mul(F::sub(lo, x1), den); hi = F::mul(F::sub(hi, x2), den); }                     // |a*b - c| < 18 r, signed-tight
+            else { lo = F::mul(lo, x1); hi = F::mul(hi, x2); }                                             // a*b in (-1.4r, 2.4r)
         };
         last_dit(u4, lo0, hi0);
         last_dit(u4 + G / 4, lo1, hi1);
         __syncthreads();
     }
-    auto first_dif = [&](uint32_t e1, const fe9& lo, const fe9& hi) {       // first DIF stage (s = 0) on h: same pairs; twiddle exponent = gidx(e1) mod n/2
+    auto first_dif = [&](uint32_t e1, const fe9& lo, const fe9& hi) {       // first DIF stage (s = 0) on d: same pairs; twiddle exponent = gidx(e1) mod n/2
         const uint32_t e2 = e1 + G / 2;
         const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
         t.put(e1, q, F::norm(F::add(lo, hi)));
@@ -269,24 +273,35 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
     }
 }
 
-// K4: contiguous DIF tail on h, then scale by n^-1 g^-j and leave Montgomery form (canonical output in [0, r)).
-__global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, size_t batch) {
+// K4: contiguous DIF tails of c (-> n S, still in the solver's 2^256 domain) and of d (-> n zeta^j D_j, 2^261 domain), then
+// h = S/2 - D/2 with ONE reduction and out of Montgomery form: c * (16 / n) - d * (zeta^-j / 2n) (canonical output in [0, r),
+// written over a).  A thread keeps its four S values in registers while the tile is reused for d.
+__global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, const fe* vc, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t Cn = 1u << Llo;
     const uint32_t b = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
     const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
     Tile t{smem, Cn * P};
-    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
-        const size_t idx = ((size_t)b << Llo) + e;
-        t.put(e, q, F::load(vh + idx * batch + q0 + q));
-    }
+    auto run_tail = [&](const fe* vec) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t e = u4 + k * (Cn / 4); const size_t idx = ((size_t)b << Llo) + e;
+            t.put(e, q, F::load(vec + idx * batch + q0 + q));
+        }
+        __syncthreads();
+        dif_run<false>(t, u4, q, Lhi, L, 0, L, Llo, b, pl, Cn);
+    };
+    run_tail(vc);
+    fe9 s0 = t.get(u4, q), s1 = t.get(u4 + Cn / 4, q), s2 = t.get(u4 + 2 * (Cn / 4), q), s3 = t.get(u4 + 3 * (Cn / 4), q);
     __syncthreads();
-    dif_run<false>(t, u4, q, Lhi, L, 0, L, Llo, b, pl, Cn);
-    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
+    run_tail(vh);
+    const fe9 kc = F::load(pl.half_c);
+    auto finish = [&](uint32_t e, const fe9& sv) {
         const size_t idx = ((size_t)b << Llo) + e;
-        F::store(vh + idx * batch + q0 + q, F::mul(t.get(e, q), F::load(pl.scale_out + idx)));
-    }
+        F::store(vh + idx * batch + q0 + q, F::fmms(sv, kc, t.get(e, q), F::load(pl.scale_out + idx)));
+    };
+    finish(u4, s0); finish(u4 + Cn / 4, s1); finish(u4 + 2 * (Cn / 4), s2); finish(u4 + 3 * (Cn / 4), s3);
 }
 
 }  // namespace
@@ -304,9 +319,9 @@ hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, siz
     opt_in(reinterpret_cast<const void*>(k_ntt_mid_contig), lds_c); opt_in(reinterpret_cast<const void*>(k_ntt_final_contig), lds_c);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch);
-    hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 3), dim3(Cn / 4 * P), lds_c, s, p, a, b, c, batch);
-    hipLaunchKernelGGL(k_ntt_pointwise_strided, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, c, batch);
-    hipLaunchKernelGGL(k_ntt_final_contig, dim3(G, pb, 1), dim3(Cn / 4 * P), lds_c, s, p, a, batch);
+    hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 2), dim3(Cn / 4 * P), lds_c, s, p, a, b, c, batch);
+    hipLaunchKernelGGL(k_ntt_pointwise_strided, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch);
+    hipLaunchKernelGGL(k_ntt_final_contig, dim3(G, pb, 1), dim3(Cn / 4 * P), lds_c, s, p, a, c, batch);
     return hipGetLastError();
 }
 

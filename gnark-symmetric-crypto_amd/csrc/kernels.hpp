@@ -23,11 +23,13 @@ void launch_decompress_g2(const uint8_t* in, G2Aff* out, uint8_t* status, size_t
 // canonical big-endian Fr -> Montgomery limbs
 void launch_fr_from_be(const uint8_t* in, fe* out, size_t n, hipStream_t s);
 void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s);
-// NTT constants for a domain of size 2^L: tw_fwd[i] = w^i, tw_inv[i] = w^-i (i < n/2, Montgomery);
-// scale_mid[pos] = n^-1 * g^bitrev(pos) (Montgomery); scale_out[pos] = n^-1 * g^-bitrev(pos) (plain, so that the
-// Montgomery product with it leaves the result in canonical form).
-void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* g, const fe* g_inv, const fe* n_inv, int L,
-                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* den_inv, int32_t* qr, hipStream_t s);
+// NTT constants for a domain of size 2^L with generator omega (Montgomery): tw_fwd[i] = w^i, tw_inv[i] = w^-i (i < n/2);
+// with zeta the primitive 2n-th root of unity whose square is omega (zeta^n = -1; derived from gnark-crypto's 2^28-th root):
+// scale_mid[pos] = n^-1 * zeta^bitrev(pos) (times the factor that moves the solver's 2^256-domain values into the NTT kernels' 2^261
+// domain); scale_out[pos] = (2n)^-1 * zeta^-bitrev(pos) and half_c = 16 / n as plain integers, so that the Montgomery products with
+// them leave the result in canonical form.  *flag |= 1 if omega is not that root's 2^(28-L)-th power (not a gnark domain).
+void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* n_inv, int L,
+                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag, hipStream_t s);
 
 // TEST HOOK: radix-2^29 field self-test.  field 0 = Fp, 1 = Fr; a, b, out: n canonical 32-byte little-endian values (device memory).
 void launch_field_ops(int field, int op, const fe* a, const fe* b, fe* out, size_t n, int chain, hipStream_t s);
@@ -64,10 +66,11 @@ void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint
 void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint32_t* status, uint8_t* cls, hipStream_t s);
 
 // ---- quotient polynomial (k_ntt.hip) ----
-struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* den_inv; const int32_t* qr; };   // tw_*, qr: 12 int32 per entry (limbs)
+struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* half_c; const int32_t* qr; };   // tw_*, qr: 12 int32 per entry (limbs)
 constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_QMAX .. NTT_QMAX (range reduction by the top limb)
-// a,b,c: [n][batch] Montgomery, first m rows valid (rows >= m are treated as zero and need not be initialised).
-// On return `a` holds h in canonical form: a[pos] = h_{bitrev(pos)} — the order pk.G1.Z is stored in.
+// a,b,c: [n][batch] Montgomery, first m rows valid (rows >= m are treated as zero and need not be initialised), c = a*b row by row
+// (a satisfied constraint system; otherwise the result is not gnark's).  On return `a` holds h in canonical form:
+// a[pos] = h_{bitrev(pos)} — the order pk.G1.Z is stored in; b and c are overwritten.
 // Domains the four kernels are written (and tested) for: workgroups of 2^ceil(L/2) and 2^floor(L/2) threads within their launch bounds.
 constexpr int NTT_MIN_LOG2 = 15, NTT_MAX_LOG2 = 17;
 // Returns the first launch-configuration error (nothing is launched when the domain is unsupported).
