@@ -70,7 +70,7 @@ EngineConfig config_from_env() {
         for (const char* q = dv; *q;) { while (*q == ',' || *q == ' ') q++; if (!*q) break; char* end = nullptr; const long v = strtol(q, &end, 10); if (end == q) throw std::runtime_error("GSC_DEVICES: expected a comma-separated list of device ordinals"); c.devices.push_back((int)v); q = end; }
     }
     c.max_batch = (size_t)env_int("GSC_MAX_BATCH", 1024);
-    c.lanes = env_int("GSC_LANES", 1);
+    c.lanes = env_int("GSC_LANES", 0);
     c.min_split = (size_t)env_int("GSC_MIN_SPLIT", 256);
     c.bit_groups = env_int("GSC_BIT_GROUPS", 1);
     c.window_z = env_int("GSC_WINDOW_Z", 0);
@@ -134,7 +134,10 @@ class AlgorithmImpl {
         calibrate();
         init_key(cs, key);
         // lanes: GSC_LANES (default 1) as long as each keeps at least 64 proofs
-        size_t nl = (size_t)cfg.lanes; if (nl < 1) nl = 1;
+        // Default: one lane for ChaCha20-V3 (its MSMs fill the chip: two lanes gain nothing), two for AES-V2, whose witness stage
+        // (445+ level launches and the commitment round trip) is latency-bound — two half batches overlap it (+4 % at batch 1024)
+        if (cfg.lanes <= 0) cfg.lanes = has_commitment ? 2 : 1;
+        size_t nl = (size_t)cfg.lanes;
         while (nl > 1 && cfg.max_batch / nl < 64) nl--;
         const size_t lane_cap = (cfg.max_batch / nl + 63) / 64 * 64;
         for (size_t i = 0; i < nl; i++) { lanes.emplace_back(new Lane); alloc_lane(*lanes.back(), lane_cap); }

@@ -192,7 +192,7 @@ algo = int(sys.argv[2])
 pk = open(sys.argv[3], "rb").read() if len(sys.argv) > 3 else golden("pk.chacha20")
 r1cs = golden(["r1cs.chacha20", "r1cs.aes128", "r1cs.aes256"][algo])
 assert g.init_algorithm(algo, pk, r1cs)
-assert "lanes=%s " % os.environ.get("GSC_LANES", "1") in g.describe(algo), g.describe(algo)
+assert "lanes=%s " % os.environ.get("GSC_LANES", "2" if algo else "1") in g.describe(algo), g.describe(algo)
 assert "devices=%d " % len(os.environ.get("GSC_DEVICES", "0").split(",")) in g.describe(algo), g.describe(algo)
 rnd = random.Random(4242)
 n = 333 if algo == 0 else 70
