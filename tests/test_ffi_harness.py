@@ -1,0 +1,47 @@
+"""integration/ffi_harness.c: libprove.so bound the way a FFI host binds it (dlopen, symbols by name, GoSlice by value,
+Prove_return by value, Free) — from plain C, with no header of this repository.  The error paths run without a GPU; one
+proof runs under -m gpu and is checked against the App. E ciphertext and with the drop-in verifier."""
+import base64
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, KAT, ROOT, golden_bytes
+
+EXE = os.path.join(ROOT, "build", "ffi_harness")
+
+
+@pytest.fixture(scope="module")
+def harness(gsc):
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-o", EXE, os.path.join(ROOT, "integration", "ffi_harness.c"), "-ldl"])
+    return EXE, gsc.LIB_PATH
+
+
+def test_error_paths_behave_like_the_reference_through_a_plain_c_binding(harness):
+    exe, lib = harness
+    out = subprocess.run([exe, lib, "errors"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "FFI-ERRORS-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_integration_sources_are_shipped_as_files():
+    for name in ("prove_gpu.go", "gpu_accept_test.go", "caller.js", "ffi_harness.c", "cpu_baseline_go.sh"):
+        assert os.path.getsize(os.path.join(ROOT, "integration", name)) > 500, name
+    go = open(os.path.join(ROOT, "integration", "prove_gpu.go")).read()
+    assert "func InitAlgorithm(algorithmID uint8, provingKey []byte, r1csData []byte) bool" in go and "func Prove(params []byte) []byte" in go
+
+
+@pytest.mark.gpu
+def test_one_proof_through_the_c_binding(harness, gsc, tmp_path):
+    exe, lib = harness
+    (tmp_path / "r1cs").write_bytes(golden_bytes("r1cs.chacha20"))
+    out = subprocess.run([exe, lib, "prove", os.path.join(GOLDEN, "pk.chacha20"), str(tmp_path / "r1cs")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    proof, ct = base64.b64decode(res["proof"]["proofJson"]), base64.b64decode(res["publicSignals"])
+    assert ct == KAT["ciphertext"] and len(proof) == 164           # the harness proves the App. E statement (core_test.go:285)
+    assert gsc.init_verifier(0, golden_bytes("vk.chacha20"))
+    sig = ct + KAT["nonce"] + KAT["counter"].to_bytes(4, "little") + KAT["input"]
+    assert gsc.verify({"cipher": "chacha20", "proof": proof, "publicSignals": sig})
