@@ -79,6 +79,7 @@ EngineConfig config_from_env() {
     c.w_table_gb = env_int("GSC_W_TABLE_GB", 16);
     c.msm_placement = env_int("GSC_MSM_PLACEMENT", 0);
     c.row_margin_bits = env_int("GSC_ROW_MARGIN_BITS", 1);
+    c.few_path = env_int("GSC_FEW_PATH", 1);
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
     if ((c.window_z && (c.window_z < 4 || c.window_z > 16)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [4,16]");
@@ -107,9 +108,11 @@ class AlgorithmImpl {
     // NOT beat one lane with the same number of proofs in flight (the MSM kernels already fill the chip and two of them thrash
     // each other's table gathers), so the default is one lane; the option stays for hosts that prefer lower per-call latency.
     struct Lane {
-        hipStream_t stream = nullptr;
+        hipStream_t stream = nullptr, side = nullptr;      // side: the assembly's scalar multiplications, beside the MSMs
+        hipEvent_t ev_ab = nullptr, ev_fs = nullptr;
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
+        size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
         size_t cap = 0;
         DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts, d_h48; DevBuf<uint32_t> d_status;
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
@@ -118,7 +121,7 @@ class AlgorithmImpl {
         DevBuf<uint4> d_digits; DevBuf<G1Xyzz> d_sj1; DevBuf<G2Xyzz> d_sj2;      // signed digits [window][octet][proof], per-window sums [window][proof]
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
         DevBuf<G1Xyzz> d_flat1; DevBuf<G2Xyzz> d_flat2;                           // sum of the flat part while the windowed part of the same set runs
-        ~Lane() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
+        ~Lane() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;
     size_t cap = 0;                     // proofs in flight over all lanes
@@ -439,8 +442,9 @@ class AlgorithmImpl {
 
     void alloc_lane(Lane& ln, size_t B) {
         ln.cap = B;
-        HIP_CHECK(hipStreamCreate(&ln.stream));
+        HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side));
         for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming));
         ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
         // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
@@ -487,9 +491,9 @@ class AlgorithmImpl {
         }
     }
     // scalars: the wire matrix W (Montgomery; wire sets) or h (canonical; Z)
-    template <class AffT, class XyzzT, class LF, class LW, class LR, class LH>
-    void run_msm(Lane& ln, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
-                 LF launch_flat, LW launch_win, LR launch_reduce, LH launch_horner) {
+    template <class AffT, class XyzzT, class LF, class LW, class LWF, class LR, class LH>
+    void run_msm(Lane& ln, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
+                 LF launch_flat, LW launch_win, LWF launch_win_few, LR launch_reduce, LH launch_horner) {
         size_t per = 0;
         if (set.nflat) {
             const size_t nslices = msm_slices(set.nflat, 1, 256, B, per);
@@ -506,7 +510,10 @@ class AlgorithmImpl {
             MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ln.d_digits.p, B, nslices, per, pa, cfg.msm_placement, 0};
             if (const char* e = getenv("GSC_MSM_EXP")) { if (getenv("GSC_ENABLE_TEST_HOOKS") && (atoi(e) & 1)) a.exp_same_entry = 1; if (atoi(e) & 2) a.placement = 1; if (atoi(e) & 4) a.placement = 0; }
             if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
-            launch_win(a, ln.stream);
+            if (n_real <= MSM_FEW_PROOFS && cfg.few_path) {      // a single Prove call: lanes = bases (columns of the padding proofs: the point at infinity)
+                HIP_CHECK(hipMemsetAsync(pa, 0, nslices * Bw * sizeof(XyzzT), ln.stream));
+                launch_win_few(a, n_real, ln.stream);
+            } else launch_win(a, ln.stream);
             if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
             reduce_slices(ln, pa, pb, nslices, Bw, sj, launch_reduce);      // slices -> one sum per (window, proof)
             launch_horner(sj, set.nwin, set.c, B, set.nflat ? flat : (XyzzT*)nullptr, sum, ln.stream);
@@ -514,10 +521,10 @@ class AlgorithmImpl {
         if (!set.nflat && !set.nwide) HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ln.stream));      // empty set: the point at infinity
     }
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
-        run_msm(ln, set, scalars, mont != 0, B, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1.p, ln.d_flat1.p, sum, timed, launch_msm_flat_g1, launch_msm_win_g1, launch_msm_reduce_g1, launch_msm_horner_g1);
+        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1.p, ln.d_flat1.p, sum, timed, launch_msm_flat_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_horner_g1);
     }
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
-        run_msm(ln, set, scalars, mont != 0, B, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, launch_msm_flat_g2, launch_msm_win_g2, launch_msm_reduce_g2, launch_msm_horner_g2);
+        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, launch_msm_flat_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_horner_g2);
     }
 
     void fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
@@ -528,6 +535,7 @@ class AlgorithmImpl {
 
     void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg) {
         const size_t B = (n + 63) / 64 * 64;
+        ln.n_real = n;
         const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
         const auto tc0 = std::chrono::steady_clock::now();
         std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs, n, B, h_in, h_rs);
@@ -581,9 +589,14 @@ class AlgorithmImpl {
         HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream));
         HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
         if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
-        // 3. MSMs
+        // 3. MSMs.  A and B1 first: the two scalar multiplications of the assembly (s * Ar, r * Bs1: 254 serial doublings) only need
+        // those two sums and run on a side stream beside the remaining MSMs.
         run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p);
         run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p);
+        HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
+        HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
+        launch_fin_scalarmul(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
+        HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
         run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p);
         run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
         run_msm_g1(ln, mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, true);
@@ -594,7 +607,8 @@ class AlgorithmImpl {
         HIP_CHECK(hipGetLastError());      // MSM launches
         HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
         // 4. assembly
-        launch_finalize(ln.d_sumA.p, ln.d_sumB1.p, ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.stream);
+        HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_fs, 0));
+        launch_fin_combine(ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, ln.d_tmp.p, B, ln.d_out.p, ln.d_flags.p, ln.stream);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
         std::vector<uint8_t> h_out(256 * B), h_flags(ln.d_flags.n); std::vector<uint32_t> h_status(B);

@@ -194,11 +194,11 @@ void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out
 void launch_challenge_from_hash(const uint8_t* h48, fe* commit, size_t batch, hipStream_t s) {
     hipLaunchKernelGGL(k_challenge_from_hash, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, h48, commit, batch);
 }
-void launch_finalize(const G1Xyzz* sumA, const G1Xyzz* sumB1, const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ,
-                     const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
-    const unsigned nb = (unsigned)((batch + 63) / 64);
-    hipLaunchKernelGGL(k_fin_scalarmul, dim3(nb, 2), dim3(64), 0, s, sumA, sumB1, rs, batch, tmp, out, flags);
-    hipLaunchKernelGGL(k_fin_combine, dim3(nb, 2), dim3(64), 0, s, sumB2, sumK, sumZ, tmp, batch, out, flags);
+void launch_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
+    hipLaunchKernelGGL(k_fin_scalarmul, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumA, sumB1, rs, batch, tmp, out, flags);
+}
+void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_fin_combine, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumB2, sumK, sumZ, tmp, batch, out, flags);
 }
 
 }  // namespace gsc

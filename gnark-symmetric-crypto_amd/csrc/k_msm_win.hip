@@ -235,6 +235,48 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArg
     C::store_xyzz(reinterpret_cast<fe*>(a.partial) + ((slice * a.nwin + j) * a.batch + p) * (4 * F::WORDS), acc);
 }
 
+// The latency path: a handful of proofs (a single Prove call).  With lanes = proofs a wave would do 64 additions per useful one, so
+// here lanes are BASES: every lane fetches the entry of its own (base, window) for ONE proof, lanes add up 64-base chunks of the
+// slice independently and a __shfl_xor butterfly of six exact additions folds the wave.  Same partial sums, ~10x less work for
+// one proof; the crossover with the batch kernel is around ten proofs.  grid: (nslices * nwin, nproofs).
+__device__ __forceinline__ fe9 shfl_xor_e(const fe9& v, int m) {
+    fe9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = __shfl_xor(v.l[i], m);
+    return r;
+}
+__device__ __forceinline__ fe9x2 shfl_xor_e(const fe9x2& v, int m) { return fe9x2{shfl_xor_e(v.a0, m), shfl_xor_e(v.a1, m)}; }
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_win_few(MsmWinArgs a) {
+    using C = Curve9<F>;
+    const size_t slice = blockIdx.x / (uint32_t)a.nwin, p = blockIdx.y, noct = (a.nbases + 7) / 8, D = (size_t)1 << (a.c - 1);
+    const uint32_t j = blockIdx.x % (uint32_t)a.nwin, lane = threadIdx.x;
+    const size_t k0 = slice * a.per < a.nbases ? slice * a.per : a.nbases, k1 = k0 + a.per < a.nbases ? k0 + a.per : a.nbases;
+    const fe* table = reinterpret_cast<const fe*>(a.table);
+    Xyzz9<F> acc = C::infinity();
+    for (size_t kb = k0; kb < k1; kb += 64) {
+        const size_t k = kb + lane;
+        if (k < k1) {
+            const uint4 w = a.digits[((size_t)j * noct + k / 8) * a.batch + p];
+            const uint32_t s = (uint32_t)(k & 7), word = s < 2 ? w.x : s < 4 ? w.y : s < 6 ? w.z : w.w;
+            const int32_t d = (int32_t)(int16_t)(uint16_t)(word >> (16 * (s & 1)));
+            if (d) {
+                const int32_t mag = d < 0 ? -d : d;
+                const Aff9<F> e = unpack_aff(load_raw<F>(table + (k * D + (size_t)(mag - 1)) * (2 * F::WORDS)), d < 0);
+                Xyzz9<F> x = C::from_aff(Aff9<F>{e.x, F::norm(e.y)});
+                acc = C::add(acc, x);
+            }
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        Xyzz9<F> o;
+        o.x = shfl_xor_e(acc.x, m); o.y = shfl_xor_e(acc.y, m); o.zz = shfl_xor_e(acc.zz, m); o.zzz = shfl_xor_e(acc.zzz, m);
+        o.inf = __shfl_xor((int)acc.inf, m) != 0;
+        acc = C::add(acc, o);
+    }
+    if (lane == 0) C::store_xyzz(reinterpret_cast<fe*>(a.partial) + ((slice * a.nwin + j) * a.batch + p) * (4 * F::WORDS), acc);
+}
+
 // ---- flat sets ----------------------------------------------------------------------------------------------------------------------
 // Bases [k0, k1) of a flat set for one proof (lane): see k_recode_flat for the three kinds of octets.  Rows have a length of their
 // own (rowlen[k] multiples of P_k at entry rowoff[k]); a value beyond its row, or MSM_FLAT_ESCAPE, is multiplied out by
@@ -457,6 +499,8 @@ void launch_msm_recode_flat(const MsmFlatRecodeArgs& a, hipStream_t s) {
 }
 void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_win<Fp29f>, dim3((unsigned)(a.nslices * a.nwin * (a.batch / 64))), dim3(64), 0, s, a); }
 void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_win<Fp2x>, dim3((unsigned)(a.nslices * a.nwin * (a.batch / 64))), dim3(64), 0, s, a); }
+void launch_msm_win_few_g1(const MsmWinArgs& a, size_t nproofs, hipStream_t s) { hipLaunchKernelGGL(k_msm_win_few<Fp29f>, dim3((unsigned)(a.nslices * a.nwin), (unsigned)nproofs), dim3(64), 0, s, a); }
+void launch_msm_win_few_g2(const MsmWinArgs& a, size_t nproofs, hipStream_t s) { hipLaunchKernelGGL(k_msm_win_few<Fp2x>, dim3((unsigned)(a.nslices * a.nwin), (unsigned)nproofs), dim3(64), 0, s, a); }
 void launch_msm_flat_g1(const MsmFlatArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat<Fp29f>, dim3((unsigned)(a.nslices * (a.batch / 64))), dim3(64), 0, s, a); }
 void launch_msm_flat_g2(const MsmFlatArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat<Fp2x>, dim3((unsigned)(a.nslices * (a.batch / 64))), dim3(64), 0, s, a); }
 void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, const G1Xyzz* addend, G1Xyzz* out, hipStream_t s) {

@@ -123,6 +123,11 @@ struct MsmWinArgs {
 };
 void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s);
 void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s);
+// The same partial sums for the first `nproofs` proofs only (columns nproofs .. batch-1 of `partial` are not written): lanes are bases
+// instead of proofs — the latency path of a single Prove call.  Worth it below MSM_FEW_PROOFS proofs.
+constexpr size_t MSM_FEW_PROOFS = 8;
+void launch_msm_win_few_g1(const MsmWinArgs& a, size_t nproofs, hipStream_t s);
+void launch_msm_win_few_g2(const MsmWinArgs& a, size_t nproofs, hipStream_t s);
 // out[p] = sum_j 2^(c j) S[j * batch + p] (+ addend[p] when addend != nullptr)
 void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, const G1Xyzz* addend, G1Xyzz* out, hipStream_t s);
 void launch_msm_horner_g2(const G2Xyzz* S, int nwin, int c, size_t batch, const G2Xyzz* addend, G2Xyzz* out, hipStream_t s);
@@ -188,7 +193,9 @@ void launch_challenge_from_hash(const uint8_t* h48, fe* commit, size_t batch, hi
 // rs: batch x 64 B (r, s little-endian canonical).  out: batch x 256 B = Ar.x Ar.y | Bs.x.a0 Bs.x.a1 Bs.y.a0 Bs.y.a1 | Krs.x Krs.y,
 // canonical little-endian limbs; flags[proof] bit0 Ar inf, bit1 Bs inf, bit2 Krs inf (buffer zeroed by the caller,
 // 4-byte aligned, length rounded up to 4).  tmp: scratch of 2 * batch points.
-void launch_finalize(const G1Xyzz* sumA, const G1Xyzz* sumB1, const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ,
-                     const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s);
+// Two kernels: the scalar multiplications s * Ar and r * Bs1 (254 doublings each: the longest serial chain of the assembly) only need
+// sumA and sumB1, so they can run beside the remaining MSMs; the combine step needs everything.
+void launch_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s);
+void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s);
 
 }  // namespace gsc
