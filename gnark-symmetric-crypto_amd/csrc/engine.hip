@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -91,7 +92,16 @@ class AlgorithmImpl {
     Cipher cipher; EngineConfig cfg;
     size_t n_wires = 0, n_public = 0, n_constraints = 0, domain_n = 0; int L = 0;
     bool has_commitment = false;
-    std::mutex mu;
+    // lanes are handed out one chunk at a time; concurrent calls (and the chunks of one call) take whichever lane is free
+    std::mutex pool_mu; std::condition_variable pool_cv; std::vector<uint8_t> lane_busy;
+    size_t acquire_lane(int want = -1) {
+        std::unique_lock<std::mutex> l(pool_mu);
+        size_t got = 0;
+        pool_cv.wait(l, [&] { for (size_t i = 0; i < lane_busy.size(); i++) if (!lane_busy[i] && (want < 0 || (size_t)want == i)) { got = i; return true; } return false; });
+        lane_busy[got] = 1;
+        return got;
+    }
+    void release_lane(size_t i) { { std::lock_guard<std::mutex> l(pool_mu); lane_busy[i] = 0; } pool_cv.notify_all(); }
     hipStream_t stream = nullptr;   // init-time work; proving runs on the lanes' streams
     size_t table_bytes = 0;
     std::vector<uint8_t> row_class;    // per scalar row (wire), predicted by calibrate(): 0 = always 0 or 1, 1 = also -1, else the largest bit length seen (255 = unknown)
@@ -109,7 +119,7 @@ class AlgorithmImpl {
     // each other's table gathers), so the default is one lane; the option stays for hosts that prefer lower per-call latency.
     struct Lane {
         hipStream_t stream = nullptr, side = nullptr;      // side: the assembly's scalar multiplications, beside the MSMs
-        hipEvent_t ev_ab = nullptr, ev_fs = nullptr;
+        hipEvent_t ev_ab = nullptr, ev_fs = nullptr, ev_b2 = nullptr;
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
@@ -118,13 +128,17 @@ class AlgorithmImpl {
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
-        DevBuf<uint4> d_digits; DevBuf<G1Xyzz> d_sj1; DevBuf<G2Xyzz> d_sj2;      // signed digits [window][octet][proof], per-window sums [window][proof]
+        DevBuf<uint4> d_digits;                                                   // signed digits [window][octet][proof]
+        // per-window sums [window][proof] and flat-part sums [proof], one pair per set: the Horner passes of several sets are deferred
+        // and run as one launch (MsmHornerJobs), so their inputs must not share storage
+        static constexpr int NSETS = 6;      // A, B1, K, Z, Ped, PedSigma
+        DevBuf<G1Xyzz> d_sj1[NSETS], d_flat1[NSETS]; DevBuf<G2Xyzz> d_sj2, d_flat2;
+        MsmHornerJobs pending1{}, pending2{};
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
-        DevBuf<G1Xyzz> d_flat1; DevBuf<G2Xyzz> d_flat2;                           // sum of the flat part while the windowed part of the same set runs
-        ~Lane() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
+        ~Lane() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (ev_b2) (void)hipEventDestroy(ev_b2); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;
-    size_t cap = 0;                     // proofs in flight over all lanes
+    size_t cap = 0;                     // proofs per lane = the largest chunk
 
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf) : cipher(c), cfg(cf) {
         int ndev = 0;
@@ -136,15 +150,15 @@ class AlgorithmImpl {
         init_program(cs);
         calibrate();
         init_key(cs, key);
-        // lanes: GSC_LANES (default 1) as long as each keeps at least 64 proofs
-        // Default: one lane for ChaCha20-V3 (its MSMs fill the chip: two lanes gain nothing), two for AES-V2, whose witness stage
-        // (445+ level launches and the commitment round trip) is latency-bound — two half batches overlap it (+4 % at batch 1024)
+        // Lanes: every lane can hold a full batch (GSC_MAX_BATCH), so concurrent calls each get a lane of their own and the chunks of a
+        // big call spread over the free ones.  Default: one lane for ChaCha20-V3 (its MSMs fill the chip: a second lane gains
+        // nothing), two for AES-V2, whose witness stage (445+ level launches of ~56 us and the commitment round trip) is latency-bound and
+        // hides under the other lane's NTT / MSM kernels.
         if (cfg.lanes <= 0) cfg.lanes = has_commitment ? 2 : 1;
-        size_t nl = (size_t)cfg.lanes;
-        while (nl > 1 && cfg.max_batch / nl < 64) nl--;
-        const size_t lane_cap = (cfg.max_batch / nl + 63) / 64 * 64;
+        const size_t nl = (size_t)cfg.lanes, lane_cap = (cfg.max_batch + 63) / 64 * 64;
         for (size_t i = 0; i < nl; i++) { lanes.emplace_back(new Lane); alloc_lane(*lanes.back(), lane_cap); }
-        cap = lane_cap * nl;
+        lane_busy.assign(nl, 0);
+        cap = lane_cap;
         HIP_CHECK(hipStreamSynchronize(stream));
     }
     ~AlgorithmImpl() { lanes.clear(); if (stream) (void)hipStreamDestroy(stream); }
@@ -444,11 +458,11 @@ class AlgorithmImpl {
         ln.cap = B;
         HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side));
         for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
-        HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming));
         ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
         // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
-        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj1 = 0, sj2 = 0, gk = 0;
+        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0};
         auto need = [&](auto& m, size_t b, size_t& pa, size_t& pb, size_t& sj) {
             auto part = [&](size_t nb, size_t ns, size_t cols) {
                 if (ns * cols > pa) pa = ns * cols;
@@ -458,12 +472,15 @@ class AlgorithmImpl {
             if (m.nflat) { part(m.nflat, msm_slices(m.nflat, 1, 256, b, per), b); if (m.nflat / 8 * b > dg) dg = m.nflat / 8 * b; if (m.nbit / 8 * (b / 64) > gk) gk = m.nbit / 8 * (b / 64); }
             if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, 128, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
         };
+        MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma};
         for (size_t b = 64; b <= B; b += 64) {
-            for (MsmSet<G1Aff>* m : {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}) need(*m, b, p1, p1b, sj1);
+            for (int k = 0; k < Lane::NSETS; k++) need(*g1sets[k], b, p1, p1b, sj1[k]);
             need(mB2, b, p2, p2b, sj2);
         }
         ln.d_part1a.alloc(p1); ln.d_part1b.alloc(p1b); ln.d_part2a.alloc(p2); ln.d_part2b.alloc(p2b);
-        ln.d_digits.alloc(dg); ln.d_sj1.alloc(sj1); ln.d_sj2.alloc(sj2); ln.d_gok.alloc(gk ? gk : 1); ln.d_flat1.alloc(B); ln.d_flat2.alloc(B);
+        ln.d_digits.alloc(dg); ln.d_gok.alloc(gk ? gk : 1);
+        for (int k = 0; k < Lane::NSETS; k++) { ln.d_sj1[k].alloc(sj1[k] ? sj1[k] : 1); ln.d_flat1[k].alloc(g1sets[k]->nflat && g1sets[k]->nwide ? B : 1); }
+        ln.d_sj2.alloc(sj2 ? sj2 : 1); ln.d_flat2.alloc(B);
         ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
         if (has_commitment) { ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_h48.alloc(48 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B); }
     }
@@ -491,9 +508,11 @@ class AlgorithmImpl {
         }
     }
     // scalars: the wire matrix W (Montgomery; wire sets) or h (canonical; Z)
-    template <class AffT, class XyzzT, class LF, class LW, class LWF, class LR, class LH>
+    // The Horner pass of the windowed part is NOT launched here: it is queued in `pending` and flushed together with those of other
+    // sets (flush_horner_*), because each is a serial chain of 254 doublings whose duration does not depend on the batch.
+    template <class AffT, class XyzzT, class LF, class LW, class LWF, class LR>
     void run_msm(Lane& ln, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
-                 LF launch_flat, LW launch_win, LWF launch_win_few, LR launch_reduce, LH launch_horner) {
+                 MsmHornerJobs& pending, LF launch_flat, LW launch_win, LWF launch_win_few, LR launch_reduce) {
         size_t per = 0;
         if (set.nflat) {
             const size_t nslices = msm_slices(set.nflat, 1, 256, B, per);
@@ -516,16 +535,21 @@ class AlgorithmImpl {
             } else launch_win(a, ln.stream);
             if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
             reduce_slices(ln, pa, pb, nslices, Bw, sj, launch_reduce);      // slices -> one sum per (window, proof)
-            launch_horner(sj, set.nwin, set.c, B, set.nflat ? flat : (XyzzT*)nullptr, sum, ln.stream);
+            if (pending.n >= MSM_HORNER_JOBS) throw std::runtime_error("internal: too many pending Horner passes");
+            pending.job[pending.n++] = MsmHornerJob{sj, set.nflat ? flat : (XyzzT*)nullptr, sum, set.nwin, set.c};
         }
         if (!set.nflat && !set.nwide) HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ln.stream));      // empty set: the point at infinity
     }
+    int set_index(const MsmSet<G1Aff>& set) const { const MsmSet<G1Aff>* all[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}; for (int k = 0; k < Lane::NSETS; k++) if (all[k] == &set) return k; return 0; }
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
-        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1.p, ln.d_flat1.p, sum, timed, launch_msm_flat_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_horner_g1);
+        const int k = set_index(set);
+        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
     }
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
-        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, launch_msm_flat_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_horner_g2);
+        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2);
     }
+    void flush_horner_g1(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g1(ln.pending1, B, s); ln.pending1.n = 0; }
+    void flush_horner_g2(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g2(ln.pending2, B, s); ln.pending2.n = 0; }
 
     void fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
         out.resize(rows * 32);
@@ -567,6 +591,7 @@ class AlgorithmImpl {
             // committed wires (same table MSM as everything else), challenge = hash_to_field(D uncompressed), resume.
             run_levels(0, commit_level);
             run_msm_g1(ln, mPed, ln.d_W.p, 1, B, ln.d_sumD.p);
+            flush_horner_g1(ln, B, ln.stream);
             launch_points_to_affine_be(ln.d_sumD.p, B, ln.d_cpts.p, ln.d_flags.p, 8, ln.stream);
             h_cpts.resize(128 * B);
             HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 64 * B, hipMemcpyDeviceToHost, ln.stream));
@@ -593,17 +618,22 @@ class AlgorithmImpl {
         // those two sums and run on a side stream beside the remaining MSMs.
         run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p);
         run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p);
+        flush_horner_g1(ln, B, ln.stream);                                           // (AES-V2: the wide wires of A and B1; nothing for ChaCha20-V3)
         HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
         HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
         launch_fin_scalarmul(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
-        HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
         run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p);
+        if (ln.pending2.n) {                                                         // the G2 Horner chain (3x a G1 one) also goes beside the MSMs
+            HIP_CHECK(hipEventRecord(ln.ev_b2, ln.stream));
+            HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_b2, 0));
+            flush_horner_g2(ln, B, ln.side);
+        }
+        HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
         run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
         run_msm_g1(ln, mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, true);
-        if (has_commitment) {      // proof of knowledge of the commitment: same scalars over sigma * Basis
-            run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);
-            launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
-        }
+        if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
+        flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
+        if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
         HIP_CHECK(hipGetLastError());      // MSM launches
         HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
         // 4. assembly
@@ -708,10 +738,10 @@ std::string Algorithm::describe() const {
 }
 size_t Algorithm::domain_size() const { return impls_[0]->domain_n; }
 void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out) {
-    std::lock_guard<std::mutex> lock(impls_[0]->mu);
     AlgorithmImpl& a = *impls_[0];
     if (m > a.n_constraints) throw std::runtime_error("debug_compute_h: more rows than constraints");
     HIP_CHECK(hipSetDevice(a.cfg.device));
+    struct Hold { AlgorithmImpl& a; size_t i; ~Hold() { a.release_lane(i); } } hold{a, a.acquire_lane(0)};
     AlgorithmImpl::Lane& ln = *a.lanes[0];
     const size_t B = 64, cnt = m * B;
     DevBuf<uint8_t> d_be(3 * cnt * 32 + 32);
@@ -724,10 +754,10 @@ void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out)
     HIP_CHECK(hipMemcpyAsync(h_out, ln.d_A.p, a.domain_n * B * 32, hipMemcpyDeviceToHost, ln.stream));
     HIP_CHECK(hipStreamSynchronize(ln.stream));
 }
-// one replica: cut the request list into chunks (multiples of 64 proofs, at most one lane's capacity, at least two chunks per call
-// when there are two lanes and enough work) and let every lane pull chunks until none are left
+// one replica: cut the request list into chunks (multiples of 64 proofs, at most one lane's capacity; a call with at least
+// 2 * min_split statements is cut into as many chunks as there are lanes) and let worker threads pull chunks, each on whichever lane
+// is free — also the lanes that concurrent calls are not using
 static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
-    std::lock_guard<std::mutex> lock(a.mu);
     if (!n) return;
     const size_t nl = a.lanes.size(), lane_cap = a.lanes[0]->cap;
     size_t nchunks = (n + lane_cap - 1) / lane_cap;
@@ -737,21 +767,22 @@ static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t 
     nchunks = (n + chunk - 1) / chunk;
     std::atomic<size_t> next{0};
     std::exception_ptr err; std::mutex err_mu;
-    auto work = [&](size_t li) {
+    auto work = [&]() {
         try {
             HIP_CHECK(hipSetDevice(a.cfg.device));
             for (;;) {
                 const size_t c = next.fetch_add(1);
                 if (c >= nchunks) break;
                 const size_t off = c * chunk, take = n - off < chunk ? n - off : chunk;
-                a.prove_chunk(*a.lanes[li], reqs + off, take, results + off, off == 0 ? debug_first : nullptr);
+                struct Hold { AlgorithmImpl& a; size_t i; ~Hold() { a.release_lane(i); } } hold{a, a.acquire_lane()};
+                a.prove_chunk(*a.lanes[hold.i], reqs + off, take, results + off, off == 0 ? debug_first : nullptr);
             }
         } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
     };
     const size_t nthreads = nchunks < nl ? nchunks : nl;
     std::vector<std::thread> th;
-    for (size_t li = 1; li < nthreads; li++) th.emplace_back(work, li);
-    work(0);
+    for (size_t t = 1; t < nthreads; t++) th.emplace_back(work);
+    work();
     for (auto& t : th) t.join();
     if (err) std::rethrow_exception(err);
 }

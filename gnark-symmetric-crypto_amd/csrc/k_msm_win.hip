@@ -369,19 +369,23 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 2 : 1) void k_msm_flat(MsmFlatA
     C::store_xyzz(reinterpret_cast<fe*>(a.partial) + (slice * a.batch + p) * (4 * F::WORDS), acc);
 }
 
-// out[p] = sum_j 2^(c j) S[j][p] (+ addend[p]): Horner from the top window, lanes = proofs.  254 doublings per proof whatever the width.
+// out[p] = sum_j 2^(c j) S[j][p] (+ addend[p]): Horner from the top window, lanes = proofs.  254 doublings per proof whatever the width:
+// a serial chain of ~1.2 ms (G1) that does not shrink with the batch, so the independent chains of several sets run as ONE launch
+// (blockIdx.y = job).
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_horner(const fe* S, int nwin, int c, size_t batch, const fe* addend, fe* out) {
+__global__ __launch_bounds__(64) void k_msm_horner(MsmHornerJobs jobs, size_t batch) {
     using C = Curve9<F>;
+    const MsmHornerJob jb = jobs.job[blockIdx.y];
+    const fe* S = reinterpret_cast<const fe*>(jb.S); const fe* addend = reinterpret_cast<const fe*>(jb.addend);
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
-    Xyzz9<F> r = C::load_xyzz(S + ((size_t)(nwin - 1) * batch + p) * (4 * F::WORDS));
-    for (int j = nwin - 2; j >= 0; j--) {
+    Xyzz9<F> r = C::load_xyzz(S + ((size_t)(jb.nwin - 1) * batch + p) * (4 * F::WORDS));
+    for (int j = jb.nwin - 2; j >= 0; j--) {
 #pragma unroll 1
-        for (int q = 0; q < c; q++) r = C::dbl(r);
+        for (int q = 0; q < jb.c; q++) r = C::dbl(r);
         r = C::add(r, C::load_xyzz(S + ((size_t)j * batch + p) * (4 * F::WORDS)));
     }
     if (addend) r = C::add(r, C::load_xyzz(addend + p * (4 * F::WORDS)));
-    C::store_xyzz(out + p * (4 * F::WORDS), r);
+    C::store_xyzz(reinterpret_cast<fe*>(jb.out) + p * (4 * F::WORDS), r);
 }
 
 // Montgomery value of the 8 x 32-bit domain (R = 2^256, what the decompression kernels produce) -> radix-2^29 domain (R' = 2^261)
@@ -503,11 +507,11 @@ void launch_msm_win_few_g1(const MsmWinArgs& a, size_t nproofs, hipStream_t s) {
 void launch_msm_win_few_g2(const MsmWinArgs& a, size_t nproofs, hipStream_t s) { hipLaunchKernelGGL(k_msm_win_few<Fp2x>, dim3((unsigned)(a.nslices * a.nwin), (unsigned)nproofs), dim3(64), 0, s, a); }
 void launch_msm_flat_g1(const MsmFlatArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat<Fp29f>, dim3((unsigned)(a.nslices * (a.batch / 64))), dim3(64), 0, s, a); }
 void launch_msm_flat_g2(const MsmFlatArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat<Fp2x>, dim3((unsigned)(a.nslices * (a.batch / 64))), dim3(64), 0, s, a); }
-void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, const G1Xyzz* addend, G1Xyzz* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_horner<Fp29f>, dim3((unsigned)(batch / 64)), dim3(64), 0, s, reinterpret_cast<const fe*>(S), nwin, c, batch, reinterpret_cast<const fe*>(addend), reinterpret_cast<fe*>(out));
+void launch_msm_horner_g1(const MsmHornerJobs& jobs, size_t batch, hipStream_t s) {
+    if (jobs.n) hipLaunchKernelGGL(k_msm_horner<Fp29f>, dim3((unsigned)(batch / 64), (unsigned)jobs.n), dim3(64), 0, s, jobs, batch);
 }
-void launch_msm_horner_g2(const G2Xyzz* S, int nwin, int c, size_t batch, const G2Xyzz* addend, G2Xyzz* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_horner<Fp2x>, dim3((unsigned)(batch / 64)), dim3(64), 0, s, reinterpret_cast<const fe*>(S), nwin, c, batch, reinterpret_cast<const fe*>(addend), reinterpret_cast<fe*>(out));
+void launch_msm_horner_g2(const MsmHornerJobs& jobs, size_t batch, hipStream_t s) {
+    if (jobs.n) hipLaunchKernelGGL(k_msm_horner<Fp2x>, dim3((unsigned)(batch / 64), (unsigned)jobs.n), dim3(64), 0, s, jobs, batch);
 }
 void launch_build_rows_g1(const G1Aff* bases, const MsmRowSeg* segs, size_t nsegs, uint32_t cap, G1Aff* table, G1Xyzz* scratch, hipStream_t s) {
     if (nsegs) hipLaunchKernelGGL((k_build_rows<Fp29f, Fp>), dim3((unsigned)((nsegs + 63) / 64)), dim3(64), 0, s,

@@ -128,9 +128,12 @@ void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s);
 constexpr size_t MSM_FEW_PROOFS = 8;
 void launch_msm_win_few_g1(const MsmWinArgs& a, size_t nproofs, hipStream_t s);
 void launch_msm_win_few_g2(const MsmWinArgs& a, size_t nproofs, hipStream_t s);
-// out[p] = sum_j 2^(c j) S[j * batch + p] (+ addend[p] when addend != nullptr)
-void launch_msm_horner_g1(const G1Xyzz* S, int nwin, int c, size_t batch, const G1Xyzz* addend, G1Xyzz* out, hipStream_t s);
-void launch_msm_horner_g2(const G2Xyzz* S, int nwin, int c, size_t batch, const G2Xyzz* addend, G2Xyzz* out, hipStream_t s);
+// out[p] = sum_j 2^(c j) S[j * batch + p] (+ addend[p] when addend != nullptr), for up to MSM_HORNER_JOBS independent sets in one launch
+constexpr int MSM_HORNER_JOBS = 6;
+struct MsmHornerJob { const void* S; const void* addend; void* out; int nwin, c; };
+struct MsmHornerJobs { MsmHornerJob job[MSM_HORNER_JOBS]; int n; };
+void launch_msm_horner_g1(const MsmHornerJobs& jobs, size_t batch, hipStream_t s);
+void launch_msm_horner_g2(const MsmHornerJobs& jobs, size_t batch, hipStream_t s);
 
 // Flat sets.  digits[o * batch + p] = eight int16 values of octet o for proof p (k_recode_flat):
 //   bit groups  the first nbit bases (a multiple of 8) are predicted to carry scalars in {-1, 0, 1} and are taken eight at a time:
