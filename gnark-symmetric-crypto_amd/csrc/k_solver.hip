@@ -237,26 +237,33 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
 // OP_COUNT (logderivarg.countHint): out[i] = number of query rows equal to table row i.  One wave per (64 proofs, op); the
 // 256 x 64-lane histogram lives in LDS (32 KiB).  Table rows are constants (index i, value T[i]) — shape checked on the host,
 // index column checked by k_check_count_tables at InitAlgorithm — so a query is matched by reading row `index` directly.
-__global__ __launch_bounds__(64) void k_solver_count(SolverArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t s_cnt[];     // [row][lane]
-    const uint32_t lane = threadIdx.x;
+constexpr uint32_t COUNT_WAVES = 8;      // waves sharing one histogram: the queries (two dependent wire loads each) are dealt round-robin
+__global__ __launch_bounds__(64 * COUNT_WAVES) void k_solver_count(SolverArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];     // [row][lane]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const size_t p = (size_t)blockIdx.x * 64 + lane;
     const size_t batch = a.batch;
     const uint32_t nlev = a.sched[0];
     const uint32_t* lstart = a.sched + 1;
     const uint32_t* ops = a.sched + 2 + nlev;
     const uint32_t i = lstart[a.first_level] + blockIdx.y;
-    if (i >= lstart[a.first_level + 1]) return;
+    if (i >= lstart[a.first_level + 1]) return;                         // (uniform over the workgroup)
     Window win{a.prog, 0, 0, lane};
     const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)ops[i]);
     win.load(at);
     const uint32_t o0 = win.get(at + 1), ntab = win.get(at + 2), nq = win.get(at + 4);
-    for (uint32_t r = 0; r < ntab; r++) s_cnt[r * 64 + lane] = 0;
+    for (uint32_t r = wave; r < ntab; r += COUNT_WAVES) s_cnt[r * 64 + lane] = 0;
+    __syncthreads();
     const uint32_t rows_base = at + 5;
     uint32_t q = rows_base + 6 * ntab;
     bool bad = false;
 #pragma unroll 1
     for (uint32_t k = 0; k < nq; k++) {
+        if (k % COUNT_WAVES != wave) {                                   // somebody else's query: step over its two expressions
+            q += 1 + 2 * win.get(q);
+            q += 1 + 2 * win.get(q);
+            continue;
+        }
         uint32_t next;
         fe x0 = eval_expr(win, q, a.coeff, a.W, batch, p, next); q = next;
         fe x1 = eval_expr(win, q, a.coeff, a.W, batch, p, next); q = next;
@@ -266,11 +273,12 @@ __global__ __launch_bounds__(64) void k_solver_count(SolverArgs a) {
         const uint32_t idx = in_range ? c0.l[0] : 0u;
         const uint32_t cidv = a.prog[rows_base + 6 * idx + 4];          // value column of table row idx
         const fe tv = load_fe(a.coeff + cidv);
-        if (in_range && Fr::eq(x1, tv)) s_cnt[idx * 64 + lane] += 1;
+        if (in_range && Fr::eq(x1, tv)) atomicAdd(&s_cnt[idx * 64 + lane], 1u);
         else bad = true;                                                  // gnark: "query not in table"
     }
+    __syncthreads();
 #pragma unroll 1
-    for (uint32_t r = 0; r < ntab; r++) {
+    for (uint32_t r = wave; r < ntab; r += COUNT_WAVES) {
         const uint32_t c = s_cnt[r * 64 + lane];
         fe v = Fr::zero();
         if (__builtin_amdgcn_ballot_w64(c != 0) != 0) v = Fr::from_u32(c);
@@ -278,7 +286,6 @@ __global__ __launch_bounds__(64) void k_solver_count(SolverArgs a) {
     }
     if (bad) atomicMin(a.status + p, i);
 }
-
 // InitAlgorithm-time check for k_solver_count: the index constant of table row r must be r.
 __global__ void k_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -361,7 +368,7 @@ void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, cons
 }
 void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
     if (!level_width) return;
-    hipLaunchKernelGGL(k_solver_count, dim3((unsigned)(a.batch / 64), level_width), dim3(64), 256 * 64 * sizeof(uint16_t), s, a);
+    hipLaunchKernelGGL(k_solver_count, dim3((unsigned)(a.batch / 64), level_width), dim3(64 * COUNT_WAVES), 256 * 64 * sizeof(uint32_t), s, a);
 }
 void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s) {
     if (!nops) return;
