@@ -232,6 +232,7 @@ def main():
     os.environ.setdefault("GSC_MAX_BATCH", str(max(64, (per_algo + 63) // 64 * 64)))
     if workload != "mixed":      # one algorithm alone on the device: widest Z digits that fit (ChaCha c = 16: 69 GB; AES c = 15: 137 GB); mixed keeps the
         os.environ.setdefault("GSC_Z_TABLE_GB", "140")      # library defaults, under which all three algorithms are resident at once (3 x (48 + 16) GB)
+        os.environ.setdefault("GSC_W_TABLE_GB", "48")       # AES-V2 wide wires: c = 15 (42 GB) instead of 14
     import torch
     import torch.distributed as dist
     stub = args.stub_prover
