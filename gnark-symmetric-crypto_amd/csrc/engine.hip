@@ -125,7 +125,7 @@ class AlgorithmImpl {
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
         size_t cap = 0;
-        DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts, d_h48; DevBuf<uint32_t> d_status;
+        DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status;
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
@@ -483,7 +483,7 @@ class AlgorithmImpl {
         for (int k = 0; k < Lane::NSETS; k++) { ln.d_sj1[k].alloc(sj1[k] ? sj1[k] : 1); ln.d_flat1[k].alloc(g1sets[k]->nflat && g1sets[k]->nwide ? B : 1); }
         ln.d_sj2.alloc(sj2 ? sj2 : 1); ln.d_flat2.alloc(B);
         ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
-        if (has_commitment) { ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_h48.alloc(48 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B); }
+        if (has_commitment) { ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B); }
     }
 
     // Waves of an MSM launch = slices x windows x groups of 64 proofs (windows = 1 for the flat kernel).  Slices of up to `most`
@@ -589,18 +589,14 @@ class AlgorithmImpl {
         std::vector<uint8_t> h_cpts;
         if (has_commitment) {
             // Groth16 commitment (gnark "BSB22"): solve up to the commitment hint, D = sum w_j * Basis_j over the
-            // committed wires (same table MSM as everything else), challenge = hash_to_field(D uncompressed), resume.
+            // committed wires (same MSM kernels as everything else), challenge = hash_to_field(D uncompressed) on the device, resume:
+            // nothing leaves the stream.
             run_levels(0, commit_level);
             run_msm_g1(ln, mPed, ln.d_W.p, 1, B, ln.d_sumD.p);
             flush_horner_g1(ln, B, ln.stream);
             launch_points_to_affine_be(ln.d_sumD.p, B, ln.d_cpts.p, ln.d_flags.p, 8, ln.stream);
+            launch_challenge_from_point(ln.d_cpts.p, ln.d_commit.p, B, ln.stream);
             h_cpts.resize(128 * B);
-            HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 64 * B, hipMemcpyDeviceToHost, ln.stream));
-            HIP_CHECK(hipStreamSynchronize(ln.stream));
-            std::vector<uint8_t> h48(48 * B);
-            for (size_t i = 0; i < B; i++) expand_message_xmd_sha256(h_cpts.data() + 64 * i, 64, "bsb22-commitment", h48.data() + 48 * i, 48);
-            ln.d_h48.upload(h48.data(), h48.size(), ln.stream);
-            launch_challenge_from_hash(ln.d_h48.p, ln.d_commit.p, B, ln.stream);
             run_levels(commit_level, n_levels);
         } else run_levels(0, n_levels);
         HIP_CHECK(hipEventRecord(ln.ev[1], ln.stream));
@@ -646,7 +642,7 @@ class AlgorithmImpl {
         HIP_CHECK(hipMemcpyAsync(h_out.data(), ln.d_out.p, h_out.size(), hipMemcpyDeviceToHost, ln.stream));
         HIP_CHECK(hipMemcpyAsync(h_flags.data(), ln.d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, ln.stream));
         HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
-        if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data() + 64 * B, ln.d_cpts.p + 64 * B, 64 * B, hipMemcpyDeviceToHost, ln.stream));
+        if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
         const auto tc1 = std::chrono::steady_clock::now();
         HIP_CHECK(hipStreamSynchronize(ln.stream));
         const auto tc2 = std::chrono::steady_clock::now();

@@ -158,14 +158,69 @@ __global__ void k_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_
         o[32 + 4 * i] = (uint8_t)(yw >> 24); o[32 + 4 * i + 1] = (uint8_t)(yw >> 16); o[32 + 4 * i + 2] = (uint8_t)(yw >> 8); o[32 + 4 * i + 3] = (uint8_t)yw;
     }
 }
-// 384-bit big-endian integer mod r by Horner over bytes (gnark-crypto fr.Hash reduces the 48 xmd bytes the same way)
-__global__ void k_challenge_from_hash(const uint8_t* h48, fe* commit, size_t batch) {
+// ---- commitment challenge on the device (AES-V2): hash_to_field(D) with RFC 9380 expand_message_xmd(SHA-256) ----
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ void sha256_block(uint32_t st[8], const uint32_t blk[16]) {
+    const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = blk[i];
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; i++) {
+        const uint32_t t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+        const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+__device__ __forceinline__ void sha256_iv(uint32_t st[8]) {
+    const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    for (int i = 0; i < 8; i++) st[i] = iv[i];
+}
+// tail block of the three hashes: [first 32 bytes] | idx | "bsb22-commitment" | 0x10 | 0x80 | zeros | bit length — as big-endian words.
+// (b_0's last block instead starts with l_i_b_str = 00 30 00: built separately below.)
+__device__ __forceinline__ void xmd_tail(uint32_t blk[16], const uint32_t first[8], uint32_t idx) {
+    // "bsb22-commitment" = 62 73 62 32 | 32 2d 63 6f | 6d 6d 69 74 | 6d 65 6e 74
+    for (int i = 0; i < 8; i++) blk[i] = first[i];
+    blk[8] = (idx << 24) | 0x627362u; blk[9] = 0x32322d63u; blk[10] = 0x6f6d6d69u; blk[11] = 0x746d656eu; blk[12] = 0x74108000u;
+    blk[13] = 0; blk[14] = 0; blk[15] = 50 * 8;
+}
+// cpts: batch x 64 bytes (uncompressed big-endian X | Y of the commitment, as gnark's Marshal() writes it) -> commit[proof] =
+// hash_to_field(cpts[proof], DST "bsb22-commitment") in Montgomery form: 48 xmd bytes as a big-endian integer mod r
+// (gnark-crypto fr.Hash).  Replaces a device -> host -> device round trip per batch.
+__global__ void k_challenge_from_point(const uint8_t* cpts, fe* commit, size_t batch) {
     const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (p >= batch) return;
-    const uint8_t* h = h48 + 48 * p;
+    const uint32_t* m = reinterpret_cast<const uint32_t*>(cpts + 64 * p);
+    uint32_t st[8], blk[16], b0[8], b1[8], b2[8];
+    // b_0 = H(Z_pad (64 zero bytes) | msg (64) | 00 30 00 | DST | 10): 148 bytes, three blocks
+    sha256_iv(st);
+    for (int i = 0; i < 16; i++) blk[i] = 0;
+    sha256_block(st, blk);
+    for (int i = 0; i < 16; i++) blk[i] = __builtin_bswap32(m[i]);
+    sha256_block(st, blk);
+    blk[0] = 0x00300062u; blk[1] = 0x73623232u; blk[2] = 0x2d636f6du; blk[3] = 0x6d69746du; blk[4] = 0x656e7410u; blk[5] = 0x80000000u;
+    for (int i = 6; i < 15; i++) blk[i] = 0;
+    blk[15] = 148 * 8;
+    sha256_block(st, blk);
+    for (int i = 0; i < 8; i++) b0[i] = st[i];
+    // b_1 = H(b_0 | 01 | DST | 10), b_2 = H((b_0 xor b_1) | 02 | DST | 10)
+    sha256_iv(st); xmd_tail(blk, b0, 1); sha256_block(st, blk);
+    for (int i = 0; i < 8; i++) b1[i] = st[i];
+    uint32_t x[8]; for (int i = 0; i < 8; i++) x[i] = b0[i] ^ b1[i];
+    sha256_iv(st); xmd_tail(blk, x, 2); sha256_block(st, blk);
+    for (int i = 0; i < 8; i++) b2[i] = st[i];
+    // 48 bytes = b_1 | first 16 bytes of b_2, big-endian integer mod r by Horner over 32-bit words
     fe acc = Fr::zero();
-    const fe b256 = Fr::from_u32(256);
-    for (int i = 0; i < 48; i++) acc = Fr::add(Fr::mul(acc, b256), Fr::from_u32(h[i]));
+    const fe w32 = Fr::mul(Fr::from_u32(65536), Fr::from_u32(65536));
+    for (int i = 0; i < 12; i++) acc = Fr::add(Fr::mul(acc, w32), Fr::from_u32(i < 8 ? b1[i] : b2[i - 8]));
     store_fe(commit + p, acc);
 }
 
@@ -191,8 +246,8 @@ void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint
 void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s) {
     hipLaunchKernelGGL(k_points_to_affine_be, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, points, batch, out, flags, bit);
 }
-void launch_challenge_from_hash(const uint8_t* h48, fe* commit, size_t batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_challenge_from_hash, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, h48, commit, batch);
+void launch_challenge_from_point(const uint8_t* cpts, fe* commit, size_t batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_challenge_from_point, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, cpts, commit, batch);
 }
 void launch_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
     hipLaunchKernelGGL(k_fin_scalarmul, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumA, sumB1, rs, batch, tmp, out, flags);

@@ -188,8 +188,9 @@ void launch_fixed_mul_g2(const G2Aff* table, int c, int nwin, const fe* scalars,
 // Commitment helpers (AES-V2).  points: batch XYZZ sums -> out: batch x 64 B big-endian canonical X|Y
 // (gnark's uncompressed G1 encoding, the prefix of the commitment hash); flags[proof] |= bit if the point is infinity.
 void launch_points_to_affine_be(const G1Xyzz* points, size_t batch, uint8_t* out, uint8_t* flags, uint32_t bit, hipStream_t s);
-// h48: batch x 48 bytes (big-endian integers from expand_message_xmd) -> commit[proof] = value mod r, Montgomery form
-void launch_challenge_from_hash(const uint8_t* h48, fe* commit, size_t batch, hipStream_t s);
+// cpts: batch x 64 B (big-endian X | Y) -> commit[proof] = hash_to_field(cpts[proof]) with expand_message_xmd(SHA-256), DST "bsb22-commitment",
+// 48 bytes reduced mod r, Montgomery form: the commitment challenge, computed on the device (no host round trip inside a proof)
+void launch_challenge_from_point(const uint8_t* cpts, fe* commit, size_t batch, hipStream_t s);
 
 // Proof assembly: inputs are the completed sums
 //   sumA = alpha + sum A + r*delta, sumB1 = beta + sum B + s*delta, sumB2 (G2), sumK = sum K - rs*delta, sumZ.
