@@ -37,9 +37,12 @@ class Batcher {
   public:
     explicit Batcher(Algorithm* a) : algo_(a) {
         const char* e = getenv("GSC_LINGER_US"); linger_us_ = e && *e ? atoi(e) : 300;
-        worker_ = std::thread([this] { run(); });
+        // one worker per lane of the engine: while one device batch is in its latency-bound stages, the next one is already being
+        // gathered and proved on the other lane (AES-V2 has two lanes by default, ChaCha20-V3 one)
+        const size_t nw = a->lanes() ? a->lanes() : 1;
+        for (size_t i = 0; i < nw; i++) workers_.emplace_back([this] { run(); });
     }
-    ~Batcher() { { std::lock_guard<std::mutex> l(mu_); stop_ = true; } cv_.notify_all(); if (worker_.joinable()) worker_.join(); }
+    ~Batcher() { { std::lock_guard<std::mutex> l(mu_); stop_ = true; } cv_.notify_all(); for (auto& w : workers_) if (w.joinable()) w.join(); }
     // blocks until the proof is done; throws std::runtime_error if the device batch failed
     void submit(const ProofRequest& req, ProofResult& out) {
         Item it{&req, &out, false, std::string()};
@@ -58,6 +61,7 @@ class Batcher {
                 if (linger_us_ > 0 && q_.size() < algo_->max_batch()) cv_.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return stop_ || q_.size() >= algo_->max_batch(); });
                 while (!q_.empty() && take.size() < algo_->max_batch()) { take.push_back(q_.front()); q_.pop_front(); }
             }
+            if (take.empty()) continue;                    // another worker took them while this one lingered
             std::vector<ProofRequest> reqs(take.size()); std::vector<ProofResult> res(take.size());
             for (size_t i = 0; i < take.size(); i++) reqs[i] = *take[i]->req;
             std::string err;
@@ -70,7 +74,7 @@ class Batcher {
         }
     }
     Algorithm* algo_; int linger_us_ = 300; bool stop_ = false;
-    std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Item*> q_; std::thread worker_;
+    std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Item*> q_; std::vector<std::thread> workers_;
 };
 
 std::mutex g_mu;

@@ -146,11 +146,19 @@ class AlgorithmImpl {
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the GPU prover has no CPU fallback");
         HIP_CHECK(hipSetDevice(cfg.device));
         HIP_CHECK(hipStreamCreate(&stream));
+        const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t0 = now();
         R1csFile cs = parse_r1cs(r1cs, r1cs_len);
         PkFile key = parse_pk(pk, pk_len);
+        const auto t1 = now();
         init_program(cs);
         calibrate();
+        const auto t2 = now();
         init_key(cs, key);
+        const auto t3 = now();
+        if (trace) fprintf(stderr, "InitAlgorithm(%d): parse %.0f ms, solver program + calibration %.0f ms, key tables %.0f ms (%.1f GiB)\n", (int)c, ms(t0, t1), ms(t1, t2), ms(t2, t3), table_bytes / 1073741824.0);
         // Lanes: every lane can hold a full batch (GSC_MAX_BATCH), so concurrent calls each get a lane of their own and the chunks of a
         // big call spread over the free ones.  Default: one lane for ChaCha20-V3 (its MSMs fill the chip: a second lane gains
         // nothing), two for AES-V2, whose witness stage (445+ level launches of ~56 us and the commitment round trip) is latency-bound and
@@ -160,6 +168,7 @@ class AlgorithmImpl {
         for (size_t i = 0; i < nl; i++) { lanes.emplace_back(new Lane); alloc_lane(*lanes.back(), lane_cap); }
         lane_busy.assign(nl, 0);
         cap = lane_cap;
+        if (trace) fprintf(stderr, "InitAlgorithm(%d): %zu lane(s) of %zu proofs %.0f ms\n", (int)c, nl, lane_cap, ms(t3, now()));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
     ~AlgorithmImpl() { lanes.clear(); if (stream) (void)hipStreamDestroy(stream); }
@@ -442,11 +451,16 @@ class AlgorithmImpl {
         }
         auto dec1 = [this](const std::vector<uint8_t>& raw, G1Aff* out) { return decompress_g1(raw, out); };
         auto dec2 = [this](const std::vector<uint8_t>& raw, G2Aff* out) { return decompress_g2(raw, out); };
-        build_set<G1Aff, G1Xyzz>(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, false);
-        build_set<G1Aff, G1Xyzz>(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, false);
-        build_set<G1Aff, G1Xyzz>(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, false);
-        build_set<G1Aff, G1Xyzz>(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, true);      // uniform full-width scalars
-        build_set<G2Aff, G2Xyzz>(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, false);
+        const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
+        auto timed = [&](const char* what, auto&& fn) {
+            const auto a0 = std::chrono::steady_clock::now(); const size_t b0 = table_bytes; fn();
+            if (trace) fprintf(stderr, "  tables %-8s %7.0f ms %8.2f GiB\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count(), (table_bytes - b0) / 1073741824.0);
+        };
+        timed("G1.A", [&] { build_set<G1Aff, G1Xyzz>(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, false); });
+        timed("G1.B", [&] { build_set<G1Aff, G1Xyzz>(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, false); });
+        timed("G1.K", [&] { build_set<G1Aff, G1Xyzz>(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, false); });
+        timed("G1.Z", [&] { build_set<G1Aff, G1Xyzz>(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, true); });      // uniform full-width scalars
+        timed("G2.B", [&] { build_set<G2Aff, G2Xyzz>(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, false); });
         if (cs.has_commitment) {
             if (cs.n_public_committed) throw std::runtime_error("r1cs: public committed wires are not supported");
             if (key.ped_basis.size() != cs.commit_private.size() * 32) throw std::runtime_error("pk: commitment basis size does not match the r1cs");
@@ -722,6 +736,7 @@ Algorithm::~Algorithm() = default;
 Cipher Algorithm::cipher() const { return impls_[0]->cipher; }
 size_t Algorithm::max_batch() const { size_t c = 0; for (auto& i : impls_) c += i->cap; return c; }
 size_t Algorithm::devices() const { return impls_.size(); }
+size_t Algorithm::lanes() const { return impls_[0]->lanes.size(); }
 void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impls_[0]->lanes[0]->stage_ms[i]; }
 float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impls_[0]->lanes[0]->last_batch; if (nbases) *nbases = impls_[0]->mZ.nwide; return impls_[0]->lanes[0]->msm_z_kernel_ms; }
 std::string Algorithm::describe() const {

@@ -57,6 +57,7 @@ class Algorithm {
     void prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first = nullptr);
     size_t max_batch() const;      // over all devices
     size_t devices() const;
+    size_t lanes() const;          // lanes of one replica: how many device batches can be in flight per device
     std::string describe() const;    // sizes, table memory — for logs / DESIGN numbers
     // raw timing of the last prove_batch, milliseconds per stage (solve, ntt, msm, finalize), device events
     void last_stage_ms(float out[4]) const;
