@@ -1,4 +1,4 @@
-"""integration/ffi_harness.c: libprove.so bound the way a FFI host binds it (dlopen, symbols by name, GoSlice by value,
+"""integration/ffi_harness.c and integration/caller_napi.js: libprove.so bound the way a FFI host binds it (dlopen, symbols by name, GoSlice by value,
 Prove_return by value, Free) — from plain C, with no header of this repository.  The error paths run without a GPU; one
 proof runs under -m gpu and is checked against the App. E ciphertext and with the drop-in verifier."""
 import base64
@@ -26,8 +26,38 @@ def test_error_paths_behave_like_the_reference_through_a_plain_c_binding(harness
     assert out.returncode == 0 and "FFI-ERRORS-OK" in out.stdout, out.stdout + out.stderr
 
 
+def _node_addon():
+    import shutil
+    node = shutil.which("node")
+    if not node or not os.path.exists("/usr/include/node/node_api.h"):
+        pytest.skip("node / N-API headers not available")
+    addon = os.path.join(ROOT, "build", "gsc_napi.node")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-I/usr/include/node", "-o", addon, os.path.join(ROOT, "integration", "node_addon", "gsc_napi.c"), "-ldl"])
+    return node, addon
+
+
+def test_node_caller_error_values_through_the_napi_binding(gsc):
+    # a real node.js process: JS -> N-API -> dlopen'ed C-ABI (GoSlice by value) -> JSON back; the values are the reference's panic values
+    node, addon = _node_addon()
+    out = subprocess.run([node, os.path.join(ROOT, "integration", "caller_napi.js"), addon, gsc.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "NODE-ERRORS-DONE" in out.stdout, out.stdout + out.stderr
+    assert 'unknown cipher   -> "could not find prover fornope"' in out.stdout
+    assert 'syntax error     -> {"Offset":1}' in out.stdout
+    assert '"Field":"key"' in out.stdout and "garbage key file -> false" in out.stdout
+
+
+@pytest.mark.gpu
+def test_node_caller_proves_through_the_napi_binding(gsc, tmp_path):
+    node, addon = _node_addon()
+    (tmp_path / "r1cs").write_bytes(golden_bytes("r1cs.chacha20"))
+    out = subprocess.run([node, os.path.join(ROOT, "integration", "caller_napi.js"), addon, gsc.LIB_PATH, os.path.join(GOLDEN, "pk.chacha20"), str(tmp_path / "r1cs")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "NODE-PROOF-DONE" in out.stdout, out.stdout + out.stderr
+    assert "proof bytes: 164" in out.stdout and "batch of 100 all proved: true" in out.stdout
+
+
 def test_integration_sources_are_shipped_as_files():
-    for name in ("prove_gpu.go", "gpu_accept_test.go", "caller.js", "ffi_harness.c", "cpu_baseline_go.sh"):
+    for name in ("prove_gpu.go", "gpu_accept_test.go", "caller.js", "caller_napi.js", "ffi_harness.c", "cpu_baseline_go.sh", "node_addon/gsc_napi.c"):
         assert os.path.getsize(os.path.join(ROOT, "integration", name)) > 500, name
     go = open(os.path.join(ROOT, "integration", "prove_gpu.go")).read()
     assert "func InitAlgorithm(algorithmID uint8, provingKey []byte, r1csData []byte) bool" in go and "func Prove(params []byte) []byte" in go
