@@ -9,7 +9,7 @@ import random
 
 import pytest
 
-from conftest import AES
+from conftest import AES, golden_bytes
 
 pytestmark = pytest.mark.gpu
 
@@ -88,3 +88,51 @@ def test_mixed_cipher_batch(gsc_aes, gsc_chacha, oracle, chacha_oracle, aes_keys
         proof = base64.b64decode(out["proof"]["proofJson"]); ct = base64.b64decode(out["publicSignals"])
         ctr = q["counter"].to_bytes(4, "little" if q["cipher"] == "chacha20" else "big")
         assert oracle.verify(vks[q["cipher"]], q["cipher"], proof, ct + bytes(q["nonce"]) + ctr + bytes(q["input"]))
+
+
+def test_concurrent_aes_callers_across_lanes_and_ciphers(gsc_aes, gsc_chacha, oracle, aes_keys):
+    # libraries/core_test.go:44-111 (TestProveVerify) proves the three ciphers from goroutines at once.  Here 3 x 40 threads call
+    # Prove concurrently plus two ProveBatch callers per AES cipher: single calls are gathered by the per-algorithm batchers (one worker
+    # per lane), batches take whichever lane is free, small batches take the lanes-are-bases kernel — every answer must still be the
+    # caller's own proof and verify under its cipher's key.
+    import threading
+    g = gsc_aes
+    assert g.init_verifier(0, golden_bytes("vk.chacha20"))
+    for name, (algo, cipher, keylen) in AES.items():
+        assert g.init_verifier(algo, aes_keys[name][2])
+    rnd = random.Random(90210)
+    ciphers = [("chacha20", 32), ("aes-128-ctr", 16), ("aes-256-ctr", 32)]
+    singles = []
+    for i in range(120):
+        c, kl = ciphers[i % 3]
+        singles.append({"cipher": c, "key": list(rnd.randbytes(kl)), "nonce": list(rnd.randbytes(12)), "counter": rnd.getrandbits(30), "input": list(rnd.randbytes(64))})
+    batches = []
+    for b in range(4):
+        c, kl = ciphers[1 + b % 2]
+        batches.append([{"cipher": c, "key": list(rnd.randbytes(kl)), "nonce": list(rnd.randbytes(12)), "counter": rnd.getrandbits(30), "input": list(rnd.randbytes(64))} for _ in range(130 + 7 * b)])
+    out_single = [None] * len(singles); out_batch = [None] * len(batches)
+
+    def one(i):
+        out_single[i] = json.loads(g.prove(singles[i]))
+
+    def many(b):
+        out_batch[b] = g.prove_batch(batches[b])
+    threads = [threading.Thread(target=one, args=(i,)) for i in range(len(singles))] + [threading.Thread(target=many, args=(b,)) for b in range(len(batches))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+
+    def check(qo):
+        q, o = qo
+        assert isinstance(o, dict) and "proof" in o, o
+        proof = base64.b64decode(o["proof"]["proofJson"]); ct = base64.b64decode(o["publicSignals"])
+        ctr = q["counter"].to_bytes(4, "little" if q["cipher"] == "chacha20" else "big")
+        sig = ct + bytes(q["nonce"]) + ctr + bytes(q["input"])
+        return g.verify({"cipher": q["cipher"], "proof": base64.b64encode(proof).decode(), "publicSignals": base64.b64encode(sig).decode()})
+    pairs = list(zip(singles, out_single))
+    for qs, os_ in zip(batches, out_batch):
+        assert len(os_) == len(qs)
+        pairs += list(zip(qs, os_))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(16) as pool:
+        res = list(pool.map(check, pairs))
+    assert all(res), [k for k, v in enumerate(res) if not v][:10]
