@@ -81,6 +81,8 @@ EngineConfig config_from_env() {
     c.msm_placement = env_int("GSC_MSM_PLACEMENT", 0);
     c.row_margin_bits = env_int("GSC_ROW_MARGIN_BITS", 1);
     c.few_path = env_int("GSC_FEW_PATH", 1);
+    c.win_slice = (size_t)env_int("GSC_WIN_SLICE", 256);
+    if (c.win_slice < 8 || c.win_slice > 4096) throw std::runtime_error("GSC_WIN_SLICE must be in [8, 4096]");
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
     if ((c.window_z && (c.window_z < 4 || c.window_z > 16)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [4,16]");
@@ -485,7 +487,7 @@ class AlgorithmImpl {
             };
             size_t per = 0;
             if (m.nflat) { part(m.nflat, msm_slices(m.nflat, 1, 256, b, per), b); if (m.nflat / 8 * b > dg) dg = m.nflat / 8 * b; if (m.nbit / 8 * (b / 64) > gk) gk = m.nbit / 8 * (b / 64); }
-            if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, 128, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
+            if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, cfg.win_slice, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
         };
         MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma};
         for (size_t b = 64; b <= B; b += 64) {
@@ -501,7 +503,7 @@ class AlgorithmImpl {
     }
 
     // Waves of an MSM launch = slices x windows x groups of 64 proofs (windows = 1 for the flat kernel).  Slices of up to `most`
-    // bases (few partial sums to reduce, a tail of < 1 % at full batches); shorter ones when that would leave fewer than ~8k waves,
+    // bases (256: few partial sums to reduce, a tail of < 2 % at full batches; measured 64 .. 512: kernel time within 1 %, reductions -3 ms); shorter ones when that would leave fewer than ~8k waves,
     // so that a small batch still spreads over the whole chip.
     static size_t msm_slices(size_t nbases, size_t nwin, size_t most, size_t B, size_t& per) {
         const size_t gw = (B / 64) * nwin, want = (8192 + gw - 1) / gw;
@@ -538,7 +540,7 @@ class AlgorithmImpl {
             reduce_slices(ln, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
         }
         if (set.nwide) {
-            const size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, 128, B, per), Bw = B * (size_t)set.nwin;
+            const size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, cfg.win_slice, B, per), Bw = B * (size_t)set.nwin;
             MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ln.d_digits.p};
             launch_msm_recode(ra, ln.stream);
             MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ln.d_digits.p, B, nslices, per, pa, cfg.msm_placement, 0};

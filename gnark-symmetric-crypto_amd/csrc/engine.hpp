@@ -38,6 +38,7 @@ struct EngineConfig {
     int z_table_gb = 48, w_table_gb = 16;   // per-algorithm HBM budgets used when the widths are not given (all three algorithms of the reference fit one 288 GB device)
     int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no prediction-based layout; 1 bit groups / row lengths from a calibration witness; 2 every wire predicted a bit (test: exercises the fallbacks)
     int row_margin_bits = 1;     // GSC_ROW_MARGIN_BITS: a wire seen with k-bit values gets a row of 2^(k + margin) multiples (capped at 2^(c-1))
+    size_t win_slice = 256;      // GSC_WIN_SLICE: bases per slice of the windowed MSM kernel at full batches (measured 64 .. 512: kernel time within 1 %)
     int few_path = 1;            // GSC_FEW_PATH: calls with at most 8 statements use the lanes-are-bases MSM kernel (latency path); 0 = always the batch kernel
     int msm_placement = 0;       // GSC_MSM_PLACEMENT: workgroup placement of the MSM kernel (kernels.hpp MsmWinArgs::placement)
 };

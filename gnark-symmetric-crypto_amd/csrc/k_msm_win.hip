@@ -222,8 +222,9 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArg
         else { slice = L / GW; rem = L % GW; }
     } else if (L < S8 * GW) { const size_t xcd = L & 7, i = L >> 3; slice = (i / GW) * 8 + xcd; rem = i % GW; }
     else { slice = L / GW; rem = L % GW; }
-    const uint32_t j = (uint32_t)(rem / G);
-    const size_t p = (rem % G) * 64 + threadIdx.x;
+    // consecutive workgroups of a slice: same window, consecutive groups of proofs (placement 2: same proofs, consecutive windows)
+    const uint32_t j = a.placement == 2 ? (uint32_t)(rem % (size_t)a.nwin) : (uint32_t)(rem / G);
+    const size_t p = (a.placement == 2 ? rem / (size_t)a.nwin : rem % G) * 64 + threadIdx.x;
     const size_t k0 = slice * a.per < a.nbases ? slice * a.per : a.nbases, k1 = k0 + a.per < a.nbases ? k0 + a.per : a.nbases;
     Xyzz9<F> acc = C::infinity();
     if (k0 < k1) {

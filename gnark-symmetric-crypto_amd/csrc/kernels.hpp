@@ -118,7 +118,8 @@ struct MsmWinArgs {
     const uint4* digits; size_t batch;
     size_t nslices, per;           // per: a multiple of 8
     void* partial;                 // G1Xyzz / G2Xyzz [nslices][nwin][batch]
-    int placement;                 // workgroup -> (slice, window, proofs) map: 0 one XCD per slice, 1 four XCDs per slice (speed only)
+    int placement;                 // workgroup -> (slice, window, proofs) map: 0 one XCD per slice, 1 four XCDs per slice, 2 as 0 with consecutive
+                                   // workgroups on consecutive windows instead of proofs (speed only; measured within 1 % of each other)
     int exp_same_entry;            // MEASUREMENT ONLY (GSC_MSM_EXP=1 with test hooks on): every gather reads entry 0 — wrong sums, pure VALU time
 };
 void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s);
