@@ -38,6 +38,9 @@ Fr toxic(const uint8_t seed[32], const char* label) {
     return t.is_zero() ? Fr::one() : t;
 }
 void fr_to_le(const Fr& v, uint8_t* out) { const U256 c = v.canon(); memcpy(out, c.w, 32); }
+// toxic waste and everything derived from it in scalar form is overwritten before the memory is released
+template <class T> void wipe(std::vector<T>& v) { volatile uint8_t* p = reinterpret_cast<volatile uint8_t*>(v.data()); for (size_t i = 0; i < v.size() * sizeof(T); i++) p[i] = 0; }
+void wipe(Fr& v) { volatile uint64_t* p = v.v.w; for (int i = 0; i < 4; i++) p[i] = 0; }
 void store_mont(const Fp& v, uint8_t* out) { memcpy(out, v.v.w, 32); }
 
 struct Out {
@@ -81,8 +84,8 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
     uint8_t seed[32];
     if (seed32) memcpy(seed, seed32, 32);
     else { size_t got = 0; while (got < 32) { const ssize_t k = getrandom(seed + got, 32 - got, 0); if (k > 0) got += (size_t)k; else if (!(k < 0 && errno == EINTR)) throw std::runtime_error(std::string("getrandom failed: ") + strerror(errno)); } }
-    const Fr tau = toxic(seed, "tau"), alpha = toxic(seed, "alpha"), beta = toxic(seed, "beta"), gamma = toxic(seed, "gamma"), delta = toxic(seed, "delta"),
-             sigma = toxic(seed, "sigma"), ped_g = toxic(seed, "pedersen-g");
+    Fr tau = toxic(seed, "tau"), alpha = toxic(seed, "alpha"), beta = toxic(seed, "beta"), gamma = toxic(seed, "gamma"), delta = toxic(seed, "delta"),
+       sigma = toxic(seed, "sigma"), ped_g = toxic(seed, "pedersen-g");
     { volatile uint8_t* w = seed; for (int i = 0; i < 32; i++) w[i] = 0; }
     // domain (gnark-crypto fft.NewDomain): generator of the 2^lg-th roots from the 2^28-th root, coset shift 5
     Fr omega = fr_from_hex("2a3c09f0a58a7e8500e0a7eb8ef62abc402d111e41112ed49bd61b6e725b19f0");
@@ -90,7 +93,7 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
     const Fr omega_inv = omega.inv(), n_inv = Fr::from_u64(n).inv(), g = Fr::from_u64(5), g_inv = g.inv(), one = Fr::one();
     // Lagrange basis at tau: L_j = (tau^n - 1) / n * w^j / (tau - w^j); one batch inversion
     Fr tn = tau; for (int i = 0; i < lg; i++) tn = tn.sq();
-    const Fr zt = tn - one;
+    Fr zt = tn - one;
     std::vector<Fr> L(n);
     {
         std::vector<Fr> den(n), pre(n), wj(n);
@@ -100,6 +103,7 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
         if (run.is_zero()) throw std::runtime_error("setup: tau is a root of unity");
         Fr inv = run.inv(); const Fr scale = zt * n_inv;
         for (size_t j = n; j-- > 0;) { const Fr dj = inv * pre[j]; inv = inv * den[j]; L[j] = dj * wj[j] * scale; }
+        wipe(den); wipe(pre);
     }
     // A_i(tau), B_i(tau), C_i(tau): column sums of the R1CS matrices against the Lagrange basis
     std::vector<Fr> A(nw, Fr::zero()), B(nw, Fr::zero()), C(nw, Fr::zero());
@@ -120,7 +124,7 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
     }
     std::vector<uint8_t> committed(nw, 0);
     for (uint32_t w : cs.commit_private) committed[w] = 1;
-    const Fr gamma_inv = gamma.inv(), delta_inv = delta.inv();
+    Fr gamma_inv = gamma.inv(), delta_inv = delta.inv();
     // ---- scalars of every G1 point of the keys, in one list:  [alpha, beta, delta | A (nw) | B (nw) | K (nw) | Z (n-1) | sigma * basis (ncp)]
     const size_t ncp = cs.commit_private.size();
     const size_t oA = 3, oB = oA + nw, oK = oB + nw, oZ = oK + nw, oS = oZ + (n - 1), n1 = oS + ncp;
@@ -136,6 +140,7 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
     {   // Z[k] = tau^bitrev(k) * Z(tau) / delta, k < n - 1
         std::vector<Fr> tp(n); tp[0] = zt * delta_inv; for (size_t j = 1; j < n; j++) tp[j] = tp[j - 1] * tau;
         for (size_t k = 0; k + 1 < n; k++) { size_t br = 0; for (int b = 0; b < lg; b++) if ((k >> b) & 1) br |= (size_t)1 << (lg - 1 - b); fr_to_le(tp[br], &sc1[32 * (oZ + k)]); }
+        wipe(tp);
     }
     for (size_t j = 0; j < ncp; j++) fr_to_le(K[cs.commit_private[j]] * sigma, &sc1[32 * (oS + j)]);
     // ---- G2: [beta, gamma, delta | B (nw) | pedersen G, -sigma * G]
@@ -154,6 +159,9 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
     std::vector<uint8_t> p1(64 * n1), i1(n1), p2(128 * n2), i2(n2);
     setup_generator_muls(device, false, g1m, sc1.data(), n1, p1.data(), i1.data());
     setup_generator_muls(device, true, g2m, sc2.data(), n2, p2.data(), i2.data());
+    // from here on only group elements are needed: discard the toxic waste and every scalar derived from it
+    wipe(sc1); wipe(sc2); wipe(L); wipe(A); wipe(B); wipe(C); wipe(K);
+    for (Fr* f : {&tau, &alpha, &beta, &gamma, &delta, &sigma, &ped_g, &gamma_inv, &delta_inv, &tn, &zt}) wipe(*f);
     auto g1 = [&](Out& o, size_t idx) { put_g1(o, &p1[64 * idx], i1[idx] != 0); };
     auto g2 = [&](Out& o, size_t idx) { put_g2(o, &p2[128 * idx], i2[idx] != 0); };
     auto in_pkK = [&](size_t i) { return i >= npub && !committed[i] && !(cs.has_commitment && i == cs.commit_wire); };

@@ -41,6 +41,7 @@ void run(const uint8_t* gen_mont, const uint8_t* scalars_le, size_t n, uint8_t* 
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out, d_out.p, sizeof(AffT) * n, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(inf, d_inf.p, n, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemset(d_sc.p, 0, 32 * n));      // the scalars are toxic waste in disguise: do not leave them in freed device memory
 }
 }  // namespace
 
