@@ -81,6 +81,9 @@ EngineConfig config_from_env() {
     c.msm_placement = env_int("GSC_MSM_PLACEMENT", 0);
     c.row_margin_bits = env_int("GSC_ROW_MARGIN_BITS", 1);
     c.few_path = env_int("GSC_FEW_PATH", 1);
+    c.few_solver = env_int("GSC_FEW_SOLVER", 1);
+    c.few_workgroups = env_int("GSC_FEW_WGS", 128);
+    if (c.few_workgroups < 1 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [1, 256]");
     c.win_slice = (size_t)env_int("GSC_WIN_SLICE", 256);
     if (c.win_slice < 8 || c.win_slice > 4096) throw std::runtime_error("GSC_WIN_SLICE must be in [8, 4096]");
     if (c.max_batch < 64) c.max_batch = 64;
@@ -111,6 +114,7 @@ class AlgorithmImpl {
 
     // program
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
+    DevBuf<uint32_t> few_ops, few_terms, few_lstart;          // the same program laid out for k_solver_few (formats.hpp FewProgram)
     uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; std::vector<uint32_t> level_long; int has_div = 0;
     // NTT
     DevBuf<int32_t> tw_fwd, tw_inv, qr; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n
@@ -127,7 +131,7 @@ class AlgorithmImpl {
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
         size_t cap = 0;
-        DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status;
+        DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync;
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
@@ -186,6 +190,12 @@ class AlgorithmImpl {
         level_kind = sp.level_kind; level_long = sp.level_long;
         prog.alloc(sp.words.size()); prog.upload(sp.words.data(), sp.words.size(), stream);
         sched.alloc(sp.sched.size()); sched.upload(sp.sched.data(), sp.sched.size(), stream);
+        {
+            const FewProgram fp = build_few_program(sp);
+            few_ops.alloc(fp.ops.size() ? fp.ops.size() : 8); few_terms.alloc(fp.terms.size()); few_lstart.alloc(fp.level_start.size());
+            if (!fp.ops.empty()) few_ops.upload(fp.ops.data(), fp.ops.size(), stream);
+            few_terms.upload(fp.terms.data(), fp.terms.size(), stream); few_lstart.upload(fp.level_start.data(), fp.level_start.size(), stream);
+        }
         lookup_coeff.alloc(sp.lookup_coeff.size() ? sp.lookup_coeff.size() : 1);
         if (!sp.lookup_coeff.empty()) lookup_coeff.upload(sp.lookup_coeff.data(), sp.lookup_coeff.size(), stream);
         coeff.alloc(cs.n_coeff()); coeff_inv.alloc(cs.n_coeff());
@@ -251,7 +261,7 @@ class AlgorithmImpl {
         launch_prep_rs(d_rs.p, d_W.p, n_wires, B, has_commitment ? d_mask_in.p : nullptr, d_mask.p, stream);
         HIP_CHECK(hipMemsetAsync(d_status.p, 0xFF, B * 4, stream));
         SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, d_W.p, d_A.p, d_B.p, d_C.p, B, d_status.p,
-                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, 0u};
+                      has_commitment ? d_mask.p : nullptr, has_commitment ? d_commit.p : nullptr, has_div, 0u, nullptr};
         for (uint32_t l = 0; l < n_levels; l++) {
             sa.first_level = l; sa.n_long = level_long[l];
             if (level_kind[l]) launch_solver_count_level(sa, level_width[l], stream); else launch_solver_level(sa, level_width[l], stream);
@@ -476,7 +486,7 @@ class AlgorithmImpl {
         HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side));
         for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming));
-        ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B);
+        ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
         // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
         size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0};
@@ -513,6 +523,7 @@ class AlgorithmImpl {
         n = (nbases + per - 1) / per;
         return n ? n : 1;
     }
+    bool few_solver_wanted(size_t n, size_t B) const { return n <= MSM_FEW_PROOFS && B == 64 && cfg.few_solver; }
     template <class XyzzT, class LR>
     void reduce_slices(Lane& ln, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, XyzzT* out, LR launch_reduce) {
         XyzzT* src = pa; XyzzT* alt = pb; size_t ns = nslices;
@@ -540,13 +551,18 @@ class AlgorithmImpl {
             reduce_slices(ln, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
         }
         if (set.nwide) {
-            const size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, cfg.win_slice, B, per), Bw = B * (size_t)set.nwin;
+            // a single Prove call (lanes = bases): slices of 512 bases — 8 gathers + 6 butterfly additions per wave, and at most 64 partial
+            // sums per column, which one reduction launch folds
+            const bool few = n_real <= MSM_FEW_PROOFS && cfg.few_path;
+            size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, cfg.win_slice, B, per);
+            if (few && nslices > (set.nwide + 511) / 512) { per = 512; nslices = (set.nwide + 511) / 512; }
+            const size_t Bw = B * (size_t)set.nwin;
             MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ln.d_digits.p};
             launch_msm_recode(ra, ln.stream);
             MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ln.d_digits.p, B, nslices, per, pa, cfg.msm_placement, 0};
             if (const char* e = getenv("GSC_MSM_EXP")) { if (getenv("GSC_ENABLE_TEST_HOOKS") && (atoi(e) & 1)) a.exp_same_entry = 1; if (atoi(e) & 2) a.placement = 1; if (atoi(e) & 4) a.placement = 0; }
             if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
-            if (n_real <= MSM_FEW_PROOFS && cfg.few_path) {      // a single Prove call: lanes = bases (columns of the padding proofs: the point at infinity)
+            if (few) {      // columns of the padding proofs: the point at infinity
                 HIP_CHECK(hipMemsetAsync(pa, 0, nslices * Bw * sizeof(XyzzT), ln.stream));
                 launch_win_few(a, n_real, ln.stream);
             } else launch_win(a, ln.stream);
@@ -595,11 +611,28 @@ class AlgorithmImpl {
         launch_prep_rs(ln.d_rs.p, ln.d_W.p, n_wires, B, has_commitment ? ln.d_mask_in.p : nullptr, ln.d_mask.p, ln.stream);
         HIP_CHECK(hipMemsetAsync(ln.d_status.p, 0xFF, B * 4, ln.stream));
         SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p,
-                      has_commitment ? ln.d_mask.p : nullptr, has_commitment ? ln.d_commit.p : nullptr, has_div, 0u};
+                      has_commitment ? ln.d_mask.p : nullptr, has_commitment ? ln.d_commit.p : nullptr, has_div, 0u, nullptr};
+        DevBuf<unsigned long long> d_trace;
+        const bool strace = getenv("GSC_SOLVER_TRACE") && getenv("GSC_ENABLE_TEST_HOOKS");
+        if (strace) {
+            std::vector<unsigned long long> init(8 * (size_t)n_levels, 0ull);
+            if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[8 * l] = ~0ull;
+            d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
+        }
+        const bool few_solver = few_solver_wanted(n, B);
+        SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
+                         ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, nullptr};
         auto run_levels = [&](uint32_t from, uint32_t to) {
             for (uint32_t l = from; l < to; l++) {
                 sa.first_level = l; sa.n_long = level_long[l];
-                if (level_kind[l]) launch_solver_count_level(sa, level_width[l], ln.stream); else launch_solver_level(sa, level_width[l], ln.stream);
+                if (level_kind[l]) launch_solver_count_level(sa, level_width[l], ln.stream);
+                else if (few_solver) {                   // a run of generic levels: one launch, device-wide barriers in between
+                    uint32_t e = l + 1; while (e < to && !level_kind[e]) e++;
+                    fa.from = l; fa.to = e; fa.trace = sa.trace;
+                    HIP_CHECK(hipMemsetAsync(ln.d_fsync.p, 0, 8, ln.stream));
+                    launch_solver_few(fa, has_div, (uint32_t)cfg.few_workgroups, ln.stream);
+                    l = e - 1;
+                } else launch_solver_level(sa, level_width[l], ln.stream);
             }
         };
         std::vector<uint8_t> h_cpts;
@@ -615,6 +648,19 @@ class AlgorithmImpl {
             h_cpts.resize(128 * B);
             run_levels(commit_level, n_levels);
         } else run_levels(0, n_levels);
+        if (strace) {
+            HIP_CHECK(hipStreamSynchronize(ln.stream));
+            std::vector<unsigned long long> t(8 * (size_t)n_levels);
+            HIP_CHECK(hipMemcpy(t.data(), d_trace.p, t.size() * 8, hipMemcpyDeviceToHost));
+            fprintf(stderr, "solver trace (us after the level's first wave; stamps: op decoded, expressions, barrier, partial sums, end) width long | next level starts\n");
+            for (uint32_t l = 0; l < n_levels; l++) {
+                if (level_kind[l]) continue;
+                fprintf(stderr, "level %3u w %4u long %3u |", l, level_width[l], level_long[l]);
+                for (int k = 1; k <= 7; k++) fprintf(stderr, " %6.2f", t[8 * l + k] ? (double)(t[8 * l + k] - t[8 * l]) / 100.0 : 0.0);
+                if (l + 1 < n_levels && !level_kind[l + 1]) fprintf(stderr, " | %6.2f", (double)(t[8 * l + 8] - t[8 * l]) / 100.0);
+                fprintf(stderr, "\n");
+            }
+        }
         HIP_CHECK(hipEventRecord(ln.ev[1], ln.stream));
         if (dbg) {
             dbg->n_wires = n_wires; dbg->n_constraints = n_constraints; dbg->n = domain_n;

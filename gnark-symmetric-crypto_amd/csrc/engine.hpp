@@ -40,6 +40,8 @@ struct EngineConfig {
     int row_margin_bits = 1;     // GSC_ROW_MARGIN_BITS: a wire seen with k-bit values gets a row of 2^(k + margin) multiples (capped at 2^(c-1))
     size_t win_slice = 256;      // GSC_WIN_SLICE: bases per slice of the windowed MSM kernel at full batches (measured 64 .. 512: kernel time within 1 %)
     int few_path = 1;            // GSC_FEW_PATH: calls with at most 8 statements use the lanes-are-bases MSM kernel (latency path); 0 = always the batch kernel
+    int few_solver = 1;          // GSC_FEW_SOLVER: such calls also solve the witness with the resident lanes-are-terms kernel (k_solver_few); 0 = one launch per level
+    int few_workgroups = 128;    // GSC_FEW_WGS: its grid (workgroups of 8 waves; far fewer than the chip holds, so all are resident)
     int msm_placement = 0;       // GSC_MSM_PLACEMENT: workgroup placement of the MSM kernel (kernels.hpp MsmWinArgs::placement)
 };
 EngineConfig config_from_env();

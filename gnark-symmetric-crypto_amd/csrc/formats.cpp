@@ -416,4 +416,52 @@ SolverProgram build_solver_program(const R1csFile& cs) {
     return sp;
 }
 
+FewProgram build_few_program(const SolverProgram& sp) {
+    FewProgram fp;
+    const std::vector<uint32_t>& W = sp.words;
+    const uint32_t nlev = sp.sched[0];
+    const uint32_t* lstart = sp.sched.data() + 1;
+    const uint32_t* ops = sp.sched.data() + 2 + nlev;
+    auto expr = [&](uint32_t& q) {                    // appends the terms of the expression at word q, returns their number
+        const uint32_t n = W.at(q);
+        for (uint32_t k = 0; k < n; k++) { fp.terms.push_back(W.at(q + 1 + 2 * k)); fp.terms.push_back(W.at(q + 2 + 2 * k)); }
+        q += 1 + 2 * n;
+        return n;
+    };
+    auto desc = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7) {
+        const uint32_t d[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
+        fp.ops.insert(fp.ops.end(), d, d + 8);
+    };
+    for (uint32_t l = 0; l < nlev; l++) {
+        fp.level_start.push_back((uint32_t)(fp.ops.size() / 8));
+        if (sp.level_kind[l]) continue;
+        for (uint32_t i = lstart[l]; i < lstart[l + 1]; i++) {
+            const uint32_t at = ops[i], op = W.at(at) & 0xFF;
+            const uint32_t toff = (uint32_t)(fp.terms.size() / 2);
+            if (op == OP_R1C) {
+                uint32_t q = at + 5;
+                const uint32_t nl = expr(q), nr = expr(q), no = expr(q);
+                desc(OP_R1C | (W[at + 1] << 8), W[at + 2], W[at + 3], W[at + 4], toff, nl, nr, no);
+            } else if (op == OP_NBITS) {
+                uint32_t q = at + 3;
+                const uint32_t n = expr(q);
+                desc(OP_NBITS, W[at + 1], W[at + 2], 0, toff, n, 0, 0);
+            } else if (op == OP_LOOKUP) {
+                uint32_t q = at + 4;
+                for (uint32_t e = 0; e < W[at + 2]; e++) {
+                    const uint32_t t = (uint32_t)(fp.terms.size() / 2), n = expr(q);
+                    desc(OP_LOOKUP, W[at + 1] + e, W[at + 3], 0, t, n, 0, 0);
+                }
+            } else if (op == OP_RANDOMIZE || op == OP_COMMIT) desc(op, W[at + 1], W[at + 2], 0, 0, 0, 0, 0);
+            else throw std::runtime_error("solver: op " + std::to_string(op) + " in a generic level");
+        }
+        const size_t w = fp.ops.size() / 8 - fp.level_start.back();
+        if (w > fp.max_level_width) fp.max_level_width = w;
+    }
+    fp.level_start.push_back((uint32_t)(fp.ops.size() / 8));
+    fp.ops.insert(fp.ops.end(), 8, 0u);                 // one all-zero descriptor past the end (a wave without work may fetch it)
+    fp.terms.insert(fp.terms.end(), 2 * 128, 0u);       // a lane may fetch (not use) up to 127 pairs past an op's last term
+    return fp;
+}
+
 }  // namespace gsc

@@ -88,4 +88,20 @@ struct SolverProgram {
 };
 SolverProgram build_solver_program(const R1csFile& cs);
 
+// The same program re-laid for calls with a handful of statements (k_solver_few: one wave per (statement, op), lanes = terms):
+// fixed 8-word descriptors so that an op costs one scalar load instead of a walk through its words, the terms of its linear
+// expressions contiguous (L | R | O), a lookup op split into one descriptor per expression.
+//   R1C:        [OP_R1C | loc << 8, constraint, unknown wire, unknown coeff, term offset, nL, nR, nO]
+//   NBITS:      [OP_NBITS, out0, nOut, 0, term offset, n, 0, 0]
+//   LOOKUP:     [OP_LOOKUP, out wire, table, 0, term offset, n, 0, 0]
+//   RANDOMIZE / COMMIT: [op, out0, nOut, 0 ...]
+// level_start has n_levels + 1 entries; OP_COUNT levels are empty here (they keep their histogram kernel).
+struct FewProgram {
+    std::vector<uint32_t> ops;           // 8 words per descriptor
+    std::vector<uint32_t> terms;         // (coefficient id, wire id) pairs
+    std::vector<uint32_t> level_start;
+    size_t max_level_width = 0;
+};
+FewProgram build_few_program(const SolverProgram& sp);
+
 }  // namespace gsc

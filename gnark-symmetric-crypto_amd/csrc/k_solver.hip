@@ -126,6 +126,10 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
     const uint32_t* lstart = a.sched + 1;
     const uint32_t* ops = a.sched + 2 + nlev;
     const uint32_t lev = a.first_level;
+    auto stamp = [&](int k) {
+        if (a.trace && lane == 0) { const unsigned long long t = wall_clock64(); if (k == 0) atomicMin(a.trace + 8 * lev, t); else atomicMax(a.trace + 8 * lev + k, t); }
+    };
+    stamp(0);
     // workgroups [0, n_long): one long op each, its terms split over the WPB waves;
     // workgroups [n_long, ...): WPB short ops each, one per wave (the LDS exchange then has a single contributor)
     const bool coop = blockIdx.y < a.n_long;
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
     const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)ops[i]);
     win.load(at);
     const uint32_t op = win.get(at) & 0xFF;
+    stamp(1);
     if (op == OP_R1C || op == OP_NBITS) {
         const uint32_t f1 = win.get(at + 1), f2 = win.get(at + 2), f3 = win.get(at + 3), f4 = win.get(at + 4);
         const uint32_t nexpr = op == OP_R1C ? 3u : 1u;
@@ -150,7 +155,9 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
             for (int k = 0; k < 8; k++) s_part[e][wave][k][lane] = r.l[k];       // own slot: no cross-wave hazard in wave-per-op mode
         }
         fe v[3];
+        stamp(2);
         if (coop) { __syncthreads(); if (wave != 0) return; }
+        stamp(3);
 #pragma unroll 1
         for (uint32_t e = 0; e < nexpr; e++) {
             fe acc;
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
             }
             if (e == 0) v[0] = acc; else if (e == 1) v[1] = acc; else v[2] = acc;
         }
+        stamp(4);
         if (op == OP_NBITS) {                               // [hdr, out0, nOut, expr]
             const fe r = Fr::from_mont(v[0]);
             const fe one = Fr::one(), zero = Fr::zero();
@@ -232,6 +240,228 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
         }
     }
     if (bad) atomicMin(a.status + p, i);     // status: 0xFFFFFFFF = satisfied, else first failing op
+    stamp(5);
+}
+
+// ---- calls with a handful of statements (single Prove): k_solver_few -----------------------------------------------------------------
+// With 1..8 statements in a 64-column batch, the lanes-are-proofs kernel above leaves the chip idle and pays, per level, a kernel
+// launch, a cold walk through the instruction words and a lone wave's serial fold of every term (measured: 26 us per level, 163
+// levels for ChaCha20, 445 for AES).  Here the whole level range is ONE launch of a fixed grid that stays resident: a wave takes
+// one (statement, op) at a time with lanes = terms of its linear expressions (one load round, one Montgomery product, a short
+// reduction), and levels are separated by a device-wide barrier on an arrival counter instead of a kernel boundary.  Results
+// are written to all 64 columns (column q holds statement q mod n_real), so everything downstream sees a well-formed batch.
+// The grid is far smaller than the chip (<= 1 workgroup per CU), so every workgroup is resident; a barrier that is not reached
+// within ~2 s of polling (it cannot be, short of a fault elsewhere) raises the abort bit, every workgroup leaves, and the
+// statements are reported as failed — no wave waits forever.
+constexpr uint32_t FEW_WAVES = 8;
+constexpr uint32_t FEW_ABORT = 0x80000000u;
+constexpr uint32_t FEW_POLL_LIMIT = 1u << 21;
+
+__device__ __forceinline__ fe readlane_fe(const fe& v, uint32_t src) {
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.l[k] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], (int)src);
+    return r;
+}
+// false: the barrier was abandoned (abort bit), the caller returns
+__device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target, unsigned long long* stamps) {
+    __shared__ uint32_t s_ok;
+    __syncthreads();                         // every wave's stores have left the CU (write-through L1)
+    if (threadIdx.x == 0) {
+        if (stamps) stamps[2] = wall_clock64();
+        __threadfence();                     // release at device scope: this XCD's L2 writes back what the workgroup stored
+        if (stamps) stamps[3] = wall_clock64();
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t polls = 0, seen;
+        while ((seen = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+            if (++polls > FEW_POLL_LIMIT) { seen = __hip_atomic_fetch_or(sync, FEW_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | FEW_ABORT; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (stamps) stamps[4] = wall_clock64();
+        __threadfence();                     // acquire: drop stale lines before the next level's wire loads
+        if (stamps) stamps[5] = wall_clock64();
+        s_ok = (seen & FEW_ABORT) ? 0u : 1u;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// One op's descriptor (wave-uniform: scalar registers) and the first 128 of its terms, lane t holding terms t and t + 64: static
+// data, fetched for a wave's next item before the barrier so that only the wire values remain to be loaded after it.
+struct FewFetch { uint32_t d[8]; uint2 cw0, cw1; };
+__device__ __forceinline__ FewFetch few_fetch(const SolverFewArgs& a, uint32_t i, uint32_t lane) {
+    FewFetch f;
+    const uint32_t* d = a.ops + 8 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 8; k++) f.d[k] = d[k];
+    const uint2* terms = reinterpret_cast<const uint2*>(a.terms) + f.d[4];          // the term list is padded by 128 pairs
+    f.cw0 = terms[lane]; f.cw1 = terms[64 + lane];
+    return f;
+}
+// coefficient x wire value of one term per lane.  Nearly every wire of these circuits is a bit and most coefficients are +-1:
+// when no lane needs a real product (wave-uniform test) the 353-instruction Montgomery multiplication is skipped.
+__device__ __forceinline__ fe few_term(const fe& cf, const fe& v, uint32_t cid) {
+    const bool v0 = Fr::is_zero(v), v1 = Fr::eq(v, Fr::one());
+    const bool easy = v0 || v1 || cid == 1 || cid == 3;
+    fe r;
+    if (__builtin_amdgcn_ballot_w64(!easy) != 0) r = Fr::mul(cf, v);
+    else {
+        const fe nv = Fr::neg(v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) r.l[k] = v0 ? 0u : v1 ? cf.l[k] : cid == 1 ? v.l[k] : nv.l[k];
+    }
+    return r;
+}
+__device__ __forceinline__ fe few_wave_sum(fe sum) {
+#pragma unroll 1
+    for (int m = 32; m >= 1; m >>= 1) {
+        fe o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o.l[k] = (uint32_t)__shfl_xor((int)sum.l[k], m);
+        sum = Fr::add(sum, o);
+    }
+    return sum;
+}
+
+template <bool HAS_DIV>
+__device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch& f, uint32_t i, uint32_t p, uint32_t lane, bool mine, unsigned long long* stamps = nullptr) {
+    const uint32_t w0 = f.d[0], w1 = f.d[1], w2 = f.d[2], w3 = f.d[3], toff = f.d[4], n0 = f.d[5], n1 = f.d[6], n2 = f.d[7];
+    const uint32_t op = w0 & 0xFF, T = n0 + n1 + n2;
+    const size_t batch = a.batch;
+    fe va = Fr::zero(), vb = va, vc = va;
+    const uint2* terms = reinterpret_cast<const uint2*>(a.terms) + toff;
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < T; t0 += 128) {
+        const bool two = T > t0 + 64;                                 // wave-uniform: most ops have a handful of terms
+        uint2 cw0 = f.cw0, cw1 = f.cw1;
+        if (t0) { cw0 = terms[t0 + lane]; cw1 = terms[t0 + 64 + lane]; }
+        const bool live0 = t0 + lane < T, live1 = t0 + 64 + lane < T;
+        // a dead lane multiplies coefficient 0 (the constant 0) by coefficient 1 (the constant 1): ids checked at InitAlgorithm
+        const uint32_t cid0 = live0 ? cw0.x : 0u, cid1 = live1 ? cw1.x : 0u;
+        const fe* src0 = (!live0 || cw0.y == WIRE_CONST) ? a.coeff + 1 : a.W + (size_t)cw0.y * batch + p;
+        const fe* src1 = (!live1 || cw1.y == WIRE_CONST) ? a.coeff + 1 : a.W + (size_t)cw1.y * batch + p;
+        const fe cf0 = load_fe(a.coeff + cid0), x0 = load_fe(src0);
+        fe prod0, prod1 = Fr::zero();
+        if (two) {
+            const fe cf1 = load_fe(a.coeff + cid1), x1 = load_fe(src1);
+            prod0 = few_term(cf0, x0, cid0);
+            prod1 = few_term(cf1, x1, cid1);
+        } else prod0 = few_term(cf0, x0, cid0);
+        if (stamps && lane == 0) stamps[6] = wall_clock64() + (prod0.l[0] & prod1.l[0] & 0u);
+#pragma unroll 1
+        for (uint32_t e = 0; e < 3; e++) {
+            const uint32_t s = e == 0 ? 0u : e == 1 ? n0 : n0 + n1, n = e == 0 ? n0 : e == 1 ? n1 : n2;
+            // the expression's terms inside this chunk: [lo, hi) relative to t0, of which [lo, mid) sit in the first 64 lanes' slot
+            const uint32_t lo = s > t0 ? s - t0 : 0u, hi = s + n > t0 ? (s + n - t0 < 128u ? s + n - t0 : 128u) : 0u;
+            if (hi <= lo) continue;
+            fe sum;
+            if (hi - lo <= 6) {
+                sum = lo < 64 ? readlane_fe(prod0, lo) : readlane_fe(prod1, lo - 64);
+                for (uint32_t k = lo + 1; k < hi; k++) sum = Fr::add(sum, k < 64 ? readlane_fe(prod0, k) : readlane_fe(prod1, k - 64));
+            } else {
+                const bool in0 = lane >= lo && lane < hi, in1 = lane + 64 >= lo && lane + 64 < hi;
+                fe s0, s1;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { s0.l[k] = in0 ? prod0.l[k] : 0u; s1.l[k] = in1 ? prod1.l[k] : 0u; }
+                sum = few_wave_sum(hi > 64 ? Fr::add(s0, s1) : s0);
+            }
+            if (e == 0) va = Fr::add(va, sum); else if (e == 1) vb = Fr::add(vb, sum); else vc = Fr::add(vc, sum);
+        }
+    }
+    bool bad = false;
+    if (stamps && lane == 0) stamps[7] = wall_clock64() + (va.l[0] & vb.l[0] & vc.l[0] & 0u);
+    if (op == OP_R1C) {                                 // same rules as k_solver's OP_R1C
+        const uint32_t loc = w0 >> 8, cidx = w1, uw = w2, uc = w3;
+        fe ab;
+        {
+            const fe one = Fr::one();
+            const bool a0 = Fr::is_zero(va), a1 = Fr::eq(va, one), b0 = Fr::is_zero(vb), b1 = Fr::eq(vb, one);      // the values are wave-uniform here
+            if (b0 || b1) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) ab.l[k] = b1 ? va.l[k] : 0u;
+            } else if (a0 || a1) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) ab.l[k] = a1 ? vb.l[k] : 0u;
+            } else ab = Fr::mul(va, vb);
+        }
+        if (loc == 0) bad = !Fr::eq(ab, vc);
+        else {
+            fe wire;
+            if (loc == 3) { wire = Fr::sub(ab, vc); vc = ab; }
+            else {
+                const fe known = loc == 1 ? vb : va;
+                fe part = loc == 1 ? va : vb;
+                if (Fr::is_zero(known)) { wire = Fr::zero(); bad = !Fr::eq(ab, vc); }
+                else if (HAS_DIV) { wire = Fr::sub(Fr::mul(vc, Fr::inv(known)), part); part = Fr::add(part, wire); }
+                else { wire = Fr::zero(); bad = true; }
+                if (loc == 1) va = part; else vb = part;
+            }
+            if (uc == 3) wire = Fr::neg(wire);
+            else if (uc != 1) wire = Fr::mul(wire, load_fe(a.coeff_inv + uc));
+            if (mine) store_fe(a.W + (size_t)uw * batch + lane, wire);
+        }
+        if (mine) {
+            store_fe(a.A + (size_t)cidx * batch + lane, va);
+            store_fe(a.B + (size_t)cidx * batch + lane, vb);
+            store_fe(a.C + (size_t)cidx * batch + lane, vc);
+        }
+    } else if (op == OP_NBITS) {
+        const fe r = Fr::from_mont(va);
+        const fe one = Fr::one();
+        uint32_t limb = 0;
+#pragma unroll 1
+        for (uint32_t k = 0; k < w2; k++) {
+            if ((k & 31) == 0) limb = k < 256 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)limb_at(r, k >> 5)) : 0u;
+            const bool bit = (limb >> (k & 31)) & 1u;
+            fe v;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v.l[j] = bit ? one.l[j] : 0u;
+            if (mine) store_fe(a.W + (size_t)(w1 + k) * batch + lane, v);
+        }
+    } else if (op == OP_LOOKUP) {
+        const fe r = Fr::from_mont(va);
+        const uint32_t hi = r.l[1] | r.l[2] | r.l[3] | r.l[4] | r.l[5] | r.l[6] | r.l[7];
+        if (hi != 0 || r.l[0] >= 256) bad = true;
+        const uint32_t cid = a.lookup_coeff[w2 * 256 + (r.l[0] & 255)];
+        const fe v = load_fe(a.coeff + cid);
+        if (mine) store_fe(a.W + (size_t)w1 * batch + lane, v);
+    } else if (op == OP_RANDOMIZE || op == OP_COMMIT) {
+        const fe* src = op == OP_RANDOMIZE ? a.mask : a.commit;
+        const fe v = src ? load_fe(src + p) : Fr::zero();
+#pragma unroll 1
+        for (uint32_t k = 0; k < w2; k++) if (mine) store_fe(a.W + (size_t)(w1 + k) * batch + lane, v);
+    }
+    if (bad && lane == 0) atomicMin(a.status + p, i);
+}
+
+template <bool HAS_DIV>
+__global__ __launch_bounds__(64 * FEW_WAVES) void k_solver_few(SolverFewArgs a) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t gw = wave * gridDim.x + blockIdx.x, nw = gridDim.x * FEW_WAVES;       // neighbouring items (the long ops come first) go to different CUs
+    const uint32_t lane_mod = lane % a.n_real;
+    uint32_t epoch = 0;
+    auto op_of = [&](uint32_t l0, uint32_t it) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(l0 + it / a.n_real)); };
+    uint32_t l0 = a.level_start[a.from], l1 = a.level_start[a.from + 1];
+    FewFetch f = few_fetch(a, op_of(l0, gw < (l1 - l0) * a.n_real ? gw : 0u), lane);       // (a wave without an item fetches op 0: harmless)
+    for (uint32_t lev = a.from; lev < a.to; lev++) {
+        const uint32_t items = (l1 - l0) * a.n_real;
+        unsigned long long* stamps = a.trace && blockIdx.x == 0 ? a.trace + 8 * lev : nullptr;       // workgroup 0 only: it holds the level's first (longest) op
+        if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();
+        for (uint32_t it = gw; it < items; it += nw) {
+            const uint32_t i = op_of(l0, it);
+            const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(it % a.n_real));
+            if (it != gw) f = few_fetch(a, i, lane);
+            few_item<HAS_DIV>(a, f, i, p, lane, lane_mod == p, it == 0 ? stamps : nullptr);
+        }
+        if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
+        if (lev + 1 == a.to) break;
+        l0 = l1; l1 = a.level_start[lev + 2];
+        f = few_fetch(a, op_of(l0, gw < (l1 - l0) * a.n_real ? gw : 0u), lane);            // static data of the next level's item: in flight across the barrier
+        if (!few_grid_barrier(a.sync, ++epoch * gridDim.x, stamps)) {
+            if (threadIdx.x < a.n_real && blockIdx.x == 0) atomicMin(a.status + threadIdx.x, 0u);      // reported as unsatisfied
+            return;
+        }
+    }
 }
 
 // OP_COUNT (logderivarg.countHint): out[i] = number of query rows equal to table row i.  One wave per (64 proofs, op); the
@@ -373,6 +603,11 @@ void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStr
 void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s) {
     if (!nops) return;
     hipLaunchKernelGGL(k_check_count_tables, dim3(nops), dim3(256), 0, s, prog, coeff, count_ops, nops, flag);
+}
+void launch_solver_few(const SolverFewArgs& a, int has_div, uint32_t workgroups, hipStream_t s) {
+    if (a.from >= a.to) return;
+    if (has_div) hipLaunchKernelGGL(k_solver_few<true>, dim3(workgroups), dim3(64 * FEW_WAVES), 0, s, a);
+    else hipLaunchKernelGGL(k_solver_few<false>, dim3(workgroups), dim3(64 * FEW_WAVES), 0, s, a);
 }
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
     if (!level_width) return;

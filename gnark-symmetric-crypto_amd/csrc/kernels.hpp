@@ -53,9 +53,22 @@ struct SolverArgs {
     const fe* commit;                               // per proof commitment challenge (Montgomery) or nullptr
     int has_div;                                    // program contains divisions (R1C solved in L or R)
     uint32_t n_long;                                // the first n_long ops of the level get a whole workgroup each
+    unsigned long long* trace;                      // diagnostics (GSC_SOLVER_TRACE): per level 8 x 100 MHz clock stamps (min entry, max of 5 stages), or nullptr
 };
 // executes level a.first_level, which holds `level_width` instructions
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
+// Calls with at most MSM_FEW_PROOFS statements: levels [from, to) (none of them an OP_COUNT level) in one launch of a resident grid,
+// one wave per (statement, op), lanes = terms; program layout: formats.hpp FewProgram.  sync: two words, zeroed before the launch.
+struct SolverFewArgs {
+    const uint32_t* ops; const uint32_t* terms; const uint32_t* level_start;
+    uint32_t from, to;
+    const fe* coeff; const fe* coeff_inv; const uint32_t* lookup_coeff;
+    fe* W; fe* A; fe* B; fe* C; size_t batch; uint32_t n_real;
+    uint32_t* status; const fe* mask; const fe* commit;
+    uint32_t* sync;
+    unsigned long long* trace;                      // diagnostics (GSC_SOLVER_TRACE): per level stamps of workgroup 0 (100 MHz clock: level in, first item done, workgroup done, released, all arrived, acquired), or nullptr
+};
+void launch_solver_few(const SolverFewArgs& a, int has_div, uint32_t workgroups, hipStream_t s);
 // same for a level made of OP_COUNT ops (LDS histogram kernel)
 void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
 // *flag |= 1 if some OP_COUNT table's index column is not 0,1,2,... (InitAlgorithm-time validation)
