@@ -82,7 +82,8 @@ EngineConfig config_from_env() {
     c.row_margin_bits = env_int("GSC_ROW_MARGIN_BITS", 1);
     c.few_path = env_int("GSC_FEW_PATH", 1);
     c.few_solver = env_int("GSC_FEW_SOLVER", 1);
-    c.few_workgroups = env_int("GSC_FEW_WGS", 128);
+    c.few_workgroups = env_int("GSC_FEW_WGS", 64);
+    c.few_coherent = env_int("GSC_FEW_COHERENT", 1);
     if (c.few_workgroups < 1 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [1, 256]");
     c.win_slice = (size_t)env_int("GSC_WIN_SLICE", 256);
     if (c.win_slice < 8 || c.win_slice > 4096) throw std::runtime_error("GSC_WIN_SLICE must be in [8, 4096]");
@@ -488,6 +489,10 @@ class AlgorithmImpl {
         HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming));
         ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
+        // calls with a handful of statements (k_solver_few) write their own columns only: the others must always hold field elements
+        // (zero, later whatever an earlier call left there) because the transforms and MSMs run over whole 64-column batches
+        HIP_CHECK(hipMemsetAsync(ln.d_W.p, 0, ln.d_W.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_A.p, 0, ln.d_A.n * sizeof(fe), ln.stream));
+        HIP_CHECK(hipMemsetAsync(ln.d_B.p, 0, ln.d_B.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_C.p, 0, ln.d_C.n * sizeof(fe), ln.stream));
         // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
         size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0};
         auto need = [&](auto& m, size_t b, size_t& pa, size_t& pb, size_t& sj) {
@@ -496,7 +501,7 @@ class AlgorithmImpl {
                 if ((ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * cols > pb) pb = (ns + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * cols;
             };
             size_t per = 0;
-            if (m.nflat) { part(m.nflat, msm_slices(m.nflat, 1, 256, b, per), b); if (m.nflat / 8 * b > dg) dg = m.nflat / 8 * b; if (m.nbit / 8 * (b / 64) > gk) gk = m.nbit / 8 * (b / 64); }
+            if (m.nflat) { part(m.nflat, msm_slices(m.nflat, 1, 256, b, per), b); if (m.nflat / 8 * b > dg) dg = m.nflat / 8 * b; if (m.nbit / 8 * (b / 64) > gk) gk = m.nbit / 8 * (b / 64); if (m.nbit / 8 * MSM_FEW_PROOFS > gk) gk = m.nbit / 8 * MSM_FEW_PROOFS; }
             if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, cfg.win_slice, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
         };
         MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma};
@@ -538,17 +543,26 @@ class AlgorithmImpl {
     // scalars: the wire matrix W (Montgomery; wire sets) or h (canonical; Z)
     // The Horner pass of the windowed part is NOT launched here: it is queued in `pending` and flushed together with those of other
     // sets (flush_horner_*), because each is a serial chain of 254 doublings whose duration does not depend on the batch.
-    template <class AffT, class XyzzT, class LF, class LW, class LWF, class LR>
+    template <class AffT, class XyzzT, class LF, class LFF, class LW, class LWF, class LR>
     void run_msm(Lane& ln, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
-                 MsmHornerJobs& pending, LF launch_flat, LW launch_win, LWF launch_win_few, LR launch_reduce) {
+                 MsmHornerJobs& pending, LF launch_flat, LFF launch_flat_few, LW launch_win, LWF launch_win_few, LR launch_reduce) {
         size_t per = 0;
         if (set.nflat) {
-            const size_t nslices = msm_slices(set.nflat, 1, 256, B, per);
-            MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ln.d_digits.p, set.nbit, set.group_ok.p, ln.d_gok.p};
-            launch_msm_recode_flat(ra, ln.stream);
-            MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ln.d_digits.p, B, nslices, per, pa, set.nbit, set.sub.p, ln.d_gok.p, scalars, set.frows.p};
-            launch_flat(a, ln.stream);
-            reduce_slices(ln, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
+            MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ln.d_digits.p, set.nbit, set.group_ok.p, ln.d_gok.p, wires ? 1 : 0};
+            if (n_real <= MSM_FEW_PROOFS && cfg.few_path) {       // a single Prove call: lanes = octets of bases (columns of the padding proofs: the point at infinity)
+                const size_t nslices = ((set.nflat + 7) / 8 + 63) / 64;
+                launch_msm_recode_flat_few(ra, n_real, ln.stream);
+                HIP_CHECK(hipMemsetAsync(pa, 0, nslices * B * sizeof(XyzzT), ln.stream));
+                MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ln.d_digits.p, B, nslices, 512, pa, set.nbit, set.sub.p, ln.d_gok.p, scalars, set.frows.p};
+                launch_flat_few(a, n_real, ln.stream);
+                reduce_slices(ln, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
+            } else {
+                const size_t nslices = msm_slices(set.nflat, 1, 256, B, per);
+                launch_msm_recode_flat(ra, ln.stream);
+                MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ln.d_digits.p, B, nslices, per, pa, set.nbit, set.sub.p, ln.d_gok.p, scalars, set.frows.p};
+                launch_flat(a, ln.stream);
+                reduce_slices(ln, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
+            }
         }
         if (set.nwide) {
             // a single Prove call (lanes = bases): slices of 512 bases — 8 gathers + 6 butterfly additions per wave, and at most 64 partial
@@ -576,10 +590,10 @@ class AlgorithmImpl {
     int set_index(const MsmSet<G1Aff>& set) const { const MsmSet<G1Aff>* all[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}; for (int k = 0; k < Lane::NSETS; k++) if (all[k] == &set) return k; return 0; }
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
         const int k = set_index(set);
-        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
+        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
     }
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
-        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2);
+        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2);
     }
     void flush_horner_g1(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g1(ln.pending1, B, s); ln.pending1.n = 0; }
     void flush_horner_g2(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g2(ln.pending2, B, s); ln.pending2.n = 0; }
@@ -615,13 +629,13 @@ class AlgorithmImpl {
         DevBuf<unsigned long long> d_trace;
         const bool strace = getenv("GSC_SOLVER_TRACE") && getenv("GSC_ENABLE_TEST_HOOKS");
         if (strace) {
-            std::vector<unsigned long long> init(8 * (size_t)n_levels, 0ull);
-            if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[8 * l] = ~0ull;
+            std::vector<unsigned long long> init(16 * ((size_t)n_levels + 1), 0ull);
+            if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[16 * l] = ~0ull;
             d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
         }
         const bool few_solver = few_solver_wanted(n, B);
         SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
-                         ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, nullptr};
+                         ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, (uint32_t)cfg.few_coherent, n_levels, nullptr};
         auto run_levels = [&](uint32_t from, uint32_t to) {
             for (uint32_t l = from; l < to; l++) {
                 sa.first_level = l; sa.n_long = level_long[l];
@@ -650,14 +664,15 @@ class AlgorithmImpl {
         } else run_levels(0, n_levels);
         if (strace) {
             HIP_CHECK(hipStreamSynchronize(ln.stream));
-            std::vector<unsigned long long> t(8 * (size_t)n_levels);
+            std::vector<unsigned long long> t(16 * ((size_t)n_levels + 1));
             HIP_CHECK(hipMemcpy(t.data(), d_trace.p, t.size() * 8, hipMemcpyDeviceToHost));
-            fprintf(stderr, "solver trace (us after the level's first wave; stamps: op decoded, expressions, barrier, partial sums, end) width long | next level starts\n");
+            { const unsigned long long* w = t.data() + 16 * (size_t)n_levels; if (w[2] > w[0]) fprintf(stderr, "last launch: %.1f us, shader clock %.0f MHz\n", (double)(w[2] - w[0]) / 100.0, (double)(w[3] - w[1]) / ((double)(w[2] - w[0]) / 100.0)); }
+            fprintf(stderr, "solver trace: us after the level's first stamp (0 = not taken) | next level starts\n");
             for (uint32_t l = 0; l < n_levels; l++) {
                 if (level_kind[l]) continue;
                 fprintf(stderr, "level %3u w %4u long %3u |", l, level_width[l], level_long[l]);
-                for (int k = 1; k <= 7; k++) fprintf(stderr, " %6.2f", t[8 * l + k] ? (double)(t[8 * l + k] - t[8 * l]) / 100.0 : 0.0);
-                if (l + 1 < n_levels && !level_kind[l + 1]) fprintf(stderr, " | %6.2f", (double)(t[8 * l + 8] - t[8 * l]) / 100.0);
+                for (int k = 1; k < 13; k++) fprintf(stderr, " %6.2f", t[16 * l + k] ? (double)(t[16 * l + k] - t[16 * l]) / 100.0 : 0.0);
+                if (l + 1 < n_levels && !level_kind[l + 1]) fprintf(stderr, " | %6.2f", (double)(t[16 * l + 16] - t[16 * l]) / 100.0);
                 fprintf(stderr, "\n");
             }
         }

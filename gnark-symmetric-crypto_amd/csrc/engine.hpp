@@ -41,7 +41,8 @@ struct EngineConfig {
     size_t win_slice = 256;      // GSC_WIN_SLICE: bases per slice of the windowed MSM kernel at full batches (measured 64 .. 512: kernel time within 1 %)
     int few_path = 1;            // GSC_FEW_PATH: calls with at most 8 statements use the lanes-are-bases MSM kernel (latency path); 0 = always the batch kernel
     int few_solver = 1;          // GSC_FEW_SOLVER: such calls also solve the witness with the resident lanes-are-terms kernel (k_solver_few); 0 = one launch per level
-    int few_workgroups = 128;    // GSC_FEW_WGS: its grid (workgroups of 8 waves; far fewer than the chip holds, so all are resident)
+    int few_workgroups = 64;     // GSC_FEW_WGS: its grid (workgroups of 8 waves, one per CU; far fewer than the chip holds, so all are resident)
+    int few_coherent = 1;        // GSC_FEW_COHERENT: 1 wire values cross workgroups through device-scope accesses; 0 plain accesses + L2 write-back / invalidate at every barrier
     int msm_placement = 0;       // GSC_MSM_PLACEMENT: workgroup placement of the MSM kernel (kernels.hpp MsmWinArgs::placement)
 };
 EngineConfig config_from_env();

@@ -460,7 +460,7 @@ FewProgram build_few_program(const SolverProgram& sp) {
     }
     fp.level_start.push_back((uint32_t)(fp.ops.size() / 8));
     fp.ops.insert(fp.ops.end(), 8, 0u);                 // one all-zero descriptor past the end (a wave without work may fetch it)
-    fp.terms.insert(fp.terms.end(), 2 * 128, 0u);       // a lane may fetch (not use) up to 127 pairs past an op's last term
+    fp.terms.insert(fp.terms.end(), 2 * 256, 0u);       // a lane may fetch (not use) up to 3 x 64 pairs past an op's last term
     return fp;
 }
 

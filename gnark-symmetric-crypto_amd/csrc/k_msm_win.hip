@@ -95,12 +95,16 @@ __global__ __launch_bounds__(64) void k_recode(MsmRecodeArgs a) {
 //    then multiplies that scalar out by double-and-add: a wrong prediction costs time, never correctness);
 //  * window octets (octwin[o] >= 0): slots = the signed c-bit digits octwin[o] .. octwin[o] + 7 of the ONE scalar rows[8o]: a wide
 //    wire whose (base, window) pairs were laid out as bases of their own, with the points 2^(c j) P (tiny wide sets: no Horner pass).
-__global__ __launch_bounds__(64) void k_recode_flat(MsmFlatRecodeArgs a) {
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x, o = blockIdx.y;
-    const int32_t win0 = a.octwin ? (int32_t)uni((uint32_t)a.octwin[o]) : -1;
+// FEW = false: one wave per (64 proofs, octet), o wave-uniform, gok per (octet, wave).  FEW = true (calls with a handful of statements): lanes are
+// octets of ONE proof (blockIdx.y), gok per (octet, proof): gok[o * MSM_FEW_PROOFS + p].
+template <bool FEW>
+__device__ __forceinline__ void recode_flat_octet(const MsmFlatRecodeArgs& a, size_t o, size_t p) {
+    auto U = [](uint32_t v) { return FEW ? v : uni(v); };
+    const int32_t win0 = a.octwin ? (int32_t)U((uint32_t)a.octwin[o]) : -1;
     uint32_t w[4] = {0, 0, 0, 0};
     if (win0 >= 0) {
-        fe s = Fr::from_mont(load_fe(a.scalars + (size_t)uni(a.rows[8 * o]) * a.batch + p));
+        fe s = load_fe(a.scalars + (size_t)U(a.rows[8 * o]) * a.batch + p);
+        if (a.mont) s = Fr::from_mont(s);
         const bool ng = sign_normalise(s);
         const uint32_t c = (uint32_t)a.c, cmask = (1u << c) - 1, D = 1u << (c - 1);
         uint32_t carry = 0;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(64) void k_recode_flat(MsmFlatRecodeArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const size_t k = 8 * o + i;
-        s[i] = k < a.nbases ? load_fe(a.scalars + (size_t)uni(a.rows[k]) * a.batch + p) : fe{};
+        s[i] = k < a.nbases ? load_fe(a.scalars + (size_t)U(a.rows[k]) * a.batch + p) : fe{};
     }
     if (o < a.nbit / 8) {
         const fe minus_one = Fr::neg(Fr::one());
@@ -135,8 +139,9 @@ __global__ __launch_bounds__(64) void k_recode_flat(MsmFlatRecodeArgs a) {
             v += e1 == 0 ? w3 : (m1 == 0 ? -w3 : 0);
             w3 *= 3;
         }
-        const bool all_ok = __all(ok) && uni(a.group_ok[o]) != 0;
-        if (threadIdx.x == 0) a.gok[o * (a.batch / 64) + blockIdx.x] = all_ok ? 1 : 0;
+        const bool all_ok = (FEW ? ok : (bool)__all(ok)) && U(a.group_ok[o]) != 0;
+        if (FEW) a.gok[o * MSM_FEW_PROOFS + p] = all_ok ? 1 : 0;
+        else if (threadIdx.x == 0) a.gok[o * (a.batch / 64) + blockIdx.x] = all_ok ? 1 : 0;
         if (all_ok) { a.digits[o * a.batch + p] = make_uint4((uint32_t)v & 0xFFFFu, 0, 0, 0); return; }
     }
 #pragma unroll
@@ -150,6 +155,11 @@ __global__ __launch_bounds__(64) void k_recode_flat(MsmFlatRecodeArgs a) {
         w[i >> 1] |= ((uint32_t)d & 0xFFFFu) << (16 * (i & 1));
     }
     a.digits[o * a.batch + p] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__global__ __launch_bounds__(64) void k_recode_flat(MsmFlatRecodeArgs a) { recode_flat_octet<false>(a, blockIdx.y, (size_t)blockIdx.x * 64 + threadIdx.x); }
+__global__ __launch_bounds__(64) void k_recode_flat_few(MsmFlatRecodeArgs a) {
+    const size_t o = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (o < (a.nbases + 7) / 8) recode_flat_octet<true>(a, o, blockIdx.y);
 }
 
 // ---- gather-accumulate -------------------------------------------------------------------------------------------------------
@@ -370,6 +380,61 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 2 : 1) void k_msm_flat(MsmFlatA
     C::store_xyzz(reinterpret_cast<fe*>(a.partial) + (slice * a.batch + p) * (4 * F::WORDS), acc);
 }
 
+// The latency path of a flat set (see k_msm_win_few): lanes are OCTETS of bases for ONE proof — a bit group is one exact addition,
+// an ordinary or window octet up to eight — and a butterfly folds the wave.  partial[blockIdx.x * batch + p]; gok per (octet, proof)
+// from k_recode_flat_few.  grid: (ceil(octets / 64), nproofs).
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_flat_few(MsmFlatArgs a) {
+    using C = Curve9<F>;
+    const size_t p = blockIdx.y, noct = (a.nbases + 7) / 8, nbit8 = a.nbit / 8;
+    const size_t o = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const fe* table = reinterpret_cast<const fe*>(a.table);
+    const fe* sub = reinterpret_cast<const fe*>(a.sub);
+    Xyzz9<F> acc = C::infinity();
+    if (o < noct) {
+        const uint4 w = a.digits[o * a.batch + p];
+        const bool grp = o < nbit8 && a.gok[o * MSM_FEW_PROOFS + p] != 0;
+        const uint64_t lo = (uint64_t)w.x | ((uint64_t)w.y << 32), hi = (uint64_t)w.z | ((uint64_t)w.w << 32);
+        const uint32_t lim = grp ? 1u : (a.nbases - 8 * o < 8 ? (uint32_t)(a.nbases - 8 * o) : 8u);
+#pragma unroll 1
+        for (uint32_t i = 0; i < lim; i++) {
+            int32_t d = (int32_t)(int16_t)(uint16_t)(((i & 4) ? hi : lo) >> (16 * (i & 3)));
+            int32_t mag = d < 0 ? -d : d;
+            const fe* src;
+            if (grp) src = sub + (o * MSM_GROUP_ENTRIES + (size_t)(mag ? mag - 1 : 0)) * (2 * F::WORDS);
+            else {
+                const uint64_t off = a.rowoff[8 * o + i];
+                if ((uint32_t)mag > a.rowlen[8 * o + i]) {                 // wrong prediction (MSM_FLAT_ESCAPE has magnitude 32768 > any flat row): rare, slow, exact
+                    fe sc = fe{}; bool sneg = d < 0;
+                    if (d == MSM_FLAT_ESCAPE) { sc = Fr::from_mont(load_fe(a.scalars + (size_t)a.rows[8 * o + i] * a.batch + p)); sneg = sign_normalise(sc); }
+                    else sc.l[0] = (uint32_t)mag;
+                    const Aff9<F> P1 = unpack_aff(load_raw<F>(table + off * (2 * F::WORDS)), sneg);
+                    Xyzz9<F> Q = C::infinity();
+                    for (int b = 253; b >= 0; b--) {
+                        if (!Q.inf) Q = C::dbl(Q);
+                        uint32_t word = sc.l[0];
+#pragma unroll
+                        for (int q = 1; q < 8; q++) word = (b >> 5) == q ? sc.l[q] : word;
+                        if ((word >> (b & 31)) & 1u) Q = C::template madd<true>(Q, P1);
+                    }
+                    acc = C::add(acc, Q);
+                    d = 0; mag = 0;
+                }
+                src = table + (off + (size_t)(mag ? mag - 1 : 0)) * (2 * F::WORDS);
+            }
+            const RawAff<F> e = load_raw<F>(src);
+            if (d) acc = C::template madd<true>(acc, unpack_aff(e, d < 0));
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        Xyzz9<F> q;
+        q.x = shfl_xor_e(acc.x, m); q.y = shfl_xor_e(acc.y, m); q.zz = shfl_xor_e(acc.zz, m); q.zzz = shfl_xor_e(acc.zzz, m);
+        q.inf = __shfl_xor((int)acc.inf, m) != 0;
+        acc = C::add(acc, q);
+    }
+    if (threadIdx.x == 0) C::store_xyzz(reinterpret_cast<fe*>(a.partial) + ((size_t)blockIdx.x * a.batch + p) * (4 * F::WORDS), acc);
+}
+
 // out[p] = sum_j 2^(c j) S[j][p] (+ addend[p]): Horner from the top window, lanes = proofs.  254 doublings per proof whatever the width:
 // a serial chain of ~1.2 ms (G1) that does not shrink with the batch, so the independent chains of several sets run as ONE launch
 // (blockIdx.y = job).
@@ -499,6 +564,11 @@ void launch_msm_recode(const MsmRecodeArgs& a, hipStream_t s) {
     if (a.mont) hipLaunchKernelGGL(k_recode<true>, grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_recode<false>, grid, dim3(64), 0, s, a);
 }
+void launch_msm_recode_flat_few(const MsmFlatRecodeArgs& a, size_t nproofs, hipStream_t s) {
+    if (a.nbases) hipLaunchKernelGGL(k_recode_flat_few, dim3((unsigned)(((a.nbases + 7) / 8 + 63) / 64), (unsigned)nproofs), dim3(64), 0, s, a);
+}
+void launch_msm_flat_few_g1(const MsmFlatArgs& a, size_t nproofs, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat_few<Fp29f>, dim3((unsigned)a.nslices, (unsigned)nproofs), dim3(64), 0, s, a); }
+void launch_msm_flat_few_g2(const MsmFlatArgs& a, size_t nproofs, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat_few<Fp2x>, dim3((unsigned)a.nslices, (unsigned)nproofs), dim3(64), 0, s, a); }
 void launch_msm_recode_flat(const MsmFlatRecodeArgs& a, hipStream_t s) {
     if (a.nbases) hipLaunchKernelGGL(k_recode_flat, dim3((unsigned)(a.batch / 64), (unsigned)((a.nbases + 7) / 8)), dim3(64), 0, s, a);
 }

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
     const uint32_t* ops = a.sched + 2 + nlev;
     const uint32_t lev = a.first_level;
     auto stamp = [&](int k) {
-        if (a.trace && lane == 0) { const unsigned long long t = wall_clock64(); if (k == 0) atomicMin(a.trace + 8 * lev, t); else atomicMax(a.trace + 8 * lev + k, t); }
+        if (a.trace && lane == 0) { const unsigned long long t = wall_clock64(); if (k == 0) atomicMin(a.trace + 16 * lev, t); else atomicMax(a.trace + 16 * lev + k, t); }
     };
     stamp(0);
     // workgroups [0, n_long): one long op each, its terms split over the WPB waves;
@@ -248,8 +248,9 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
 // launch, a cold walk through the instruction words and a lone wave's serial fold of every term (measured: 26 us per level, 163
 // levels for ChaCha20, 445 for AES).  Here the whole level range is ONE launch of a fixed grid that stays resident: a wave takes
 // one (statement, op) at a time with lanes = terms of its linear expressions (one load round, one Montgomery product, a short
-// reduction), and levels are separated by a device-wide barrier on an arrival counter instead of a kernel boundary.  Results
-// are written to all 64 columns (column q holds statement q mod n_real), so everything downstream sees a well-formed batch.
+// reduction), and levels are separated by a device-wide barrier on an arrival counter instead of a kernel boundary.  Only the
+// statements' own columns are written (one lane's store per value): the other columns of the 64-wide batch keep what they held —
+// zero from the allocation or an earlier call's witness, field elements either way, which is all the transforms and MSMs ask.
 // The grid is far smaller than the chip (<= 1 workgroup per CU), so every workgroup is resident; a barrier that is not reached
 // within ~2 s of polling (it cannot be, short of a fault elsewhere) raises the abort bit, every workgroup leaves, and the
 // statements are reported as failed — no wave waits forever.
@@ -263,13 +264,33 @@ __device__ __forceinline__ fe readlane_fe(const fe& v, uint32_t src) {
     for (int k = 0; k < 8; k++) r.l[k] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], (int)src);
     return r;
 }
+// Wire values cross workgroups (and XCDs, each with an L2 of its own) inside one launch.  mode 1: they are read and written with
+// device-scope accesses (sc1: served at the memory side, write-through), so the barrier needs no cache maintenance; mode 0: plain
+// accesses, and the barrier writes the L2 back before arriving and invalidates it after leaving (what a cooperative grid sync does).
+__device__ __forceinline__ fe load_wire(const fe* p, bool dev) {
+    if (!dev) return load_fe(p);
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long v = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.l[2 * k] = (uint32_t)v; r.l[2 * k + 1] = (uint32_t)(v >> 32);
+    }
+    return r;
+}
+__device__ __forceinline__ void store_wire(fe* p, const fe& v, bool dev) {
+    if (!dev) { store_fe(p, v); return; }
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+#pragma unroll
+    for (int k = 0; k < 4; k++) __hip_atomic_store(q + k, (unsigned long long)v.l[2 * k] | ((unsigned long long)v.l[2 * k + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // false: the barrier was abandoned (abort bit), the caller returns
-__device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target, unsigned long long* stamps) {
+__device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target, unsigned long long* stamps, bool dev) {
     __shared__ uint32_t s_ok;
     __syncthreads();                         // every wave's stores have left the CU (write-through L1)
     if (threadIdx.x == 0) {
         if (stamps) stamps[2] = wall_clock64();
-        __threadfence();                     // release at device scope: this XCD's L2 writes back what the workgroup stored
+        if (!dev) __threadfence();           // release at device scope: this XCD's L2 writes back what the workgroup stored
         if (stamps) stamps[3] = wall_clock64();
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t polls = 0, seen;
@@ -278,7 +299,7 @@ __device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target
             __builtin_amdgcn_s_sleep(2);
         }
         if (stamps) stamps[4] = wall_clock64();
-        __threadfence();                     // acquire: drop stale lines before the next level's wire loads
+        if (!dev) __threadfence();           // acquire: drop stale lines before the next level's wire loads
         if (stamps) stamps[5] = wall_clock64();
         s_ok = (seen & FEW_ABORT) ? 0u : 1u;
     }
@@ -286,31 +307,19 @@ __device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target
     return s_ok != 0;
 }
 
-// One op's descriptor (wave-uniform: scalar registers) and the first 128 of its terms, lane t holding terms t and t + 64: static
-// data, fetched for a wave's next item before the barrier so that only the wire values remain to be loaded after it.
-struct FewFetch { uint32_t d[8]; uint2 cw0, cw1; };
+// One op's descriptor (wave-uniform: scalar registers) and the first FEW_SLOTS x 64 of its terms, lane t holding terms t, t + 64,
+// ..: static data, fetched for a wave's next item before the barrier so that only the wire values remain to be loaded after it.
+constexpr int FEW_SLOTS = 3;             // ChaCha20's add32 rows have 96 + 1 + 33 terms
+struct FewFetch { uint32_t d[8]; uint2 cw[FEW_SLOTS]; };
 __device__ __forceinline__ FewFetch few_fetch(const SolverFewArgs& a, uint32_t i, uint32_t lane) {
     FewFetch f;
     const uint32_t* d = a.ops + 8 * (size_t)i;
 #pragma unroll
     for (int k = 0; k < 8; k++) f.d[k] = d[k];
-    const uint2* terms = reinterpret_cast<const uint2*>(a.terms) + f.d[4];          // the term list is padded by 128 pairs
-    f.cw0 = terms[lane]; f.cw1 = terms[64 + lane];
-    return f;
-}
-// coefficient x wire value of one term per lane.  Nearly every wire of these circuits is a bit and most coefficients are +-1:
-// when no lane needs a real product (wave-uniform test) the 353-instruction Montgomery multiplication is skipped.
-__device__ __forceinline__ fe few_term(const fe& cf, const fe& v, uint32_t cid) {
-    const bool v0 = Fr::is_zero(v), v1 = Fr::eq(v, Fr::one());
-    const bool easy = v0 || v1 || cid == 1 || cid == 3;
-    fe r;
-    if (__builtin_amdgcn_ballot_w64(!easy) != 0) r = Fr::mul(cf, v);
-    else {
-        const fe nv = Fr::neg(v);
+    const uint2* terms = reinterpret_cast<const uint2*>(a.terms) + f.d[4];          // the term list is padded by FEW_SLOTS x 64 pairs
 #pragma unroll
-        for (int k = 0; k < 8; k++) r.l[k] = v0 ? 0u : v1 ? cf.l[k] : cid == 1 ? v.l[k] : nv.l[k];
-    }
-    return r;
+    for (int j = 0; j < FEW_SLOTS; j++) f.cw[j] = terms[64 * j + lane];
+    return f;
 }
 __device__ __forceinline__ fe few_wave_sum(fe sum) {
 #pragma unroll 1
@@ -322,48 +331,92 @@ __device__ __forceinline__ fe few_wave_sum(fe sum) {
     }
     return sum;
 }
+__device__ __forceinline__ fe pick_slot(const fe (&v)[FEW_SLOTS], uint32_t j) {
+    fe r = v[0];
+#pragma unroll
+    for (int k = 1; k < FEW_SLOTS; k++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = j == (uint32_t)k ? v[k].l[i] : r.l[i];
+    }
+    return r;
+}
 
 template <bool HAS_DIV>
-__device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch& f, uint32_t i, uint32_t p, uint32_t lane, bool mine, unsigned long long* stamps = nullptr) {
+__device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch& f, uint32_t i, uint32_t p, uint32_t lane, unsigned long long* stamps = nullptr) {
     const uint32_t w0 = f.d[0], w1 = f.d[1], w2 = f.d[2], w3 = f.d[3], toff = f.d[4], n0 = f.d[5], n1 = f.d[6], n2 = f.d[7];
     const uint32_t op = w0 & 0xFF, T = n0 + n1 + n2;
     const size_t batch = a.batch;
+    const bool dev = a.coherent != 0;
+    constexpr uint32_t CHUNK = 64 * FEW_SLOTS;
     fe va = Fr::zero(), vb = va, vc = va;
     const uint2* terms = reinterpret_cast<const uint2*>(a.terms) + toff;
 #pragma unroll 1
-    for (uint32_t t0 = 0; t0 < T; t0 += 128) {
-        const bool two = T > t0 + 64;                                 // wave-uniform: most ops have a handful of terms
-        uint2 cw0 = f.cw0, cw1 = f.cw1;
-        if (t0) { cw0 = terms[t0 + lane]; cw1 = terms[t0 + 64 + lane]; }
-        const bool live0 = t0 + lane < T, live1 = t0 + 64 + lane < T;
-        // a dead lane multiplies coefficient 0 (the constant 0) by coefficient 1 (the constant 1): ids checked at InitAlgorithm
-        const uint32_t cid0 = live0 ? cw0.x : 0u, cid1 = live1 ? cw1.x : 0u;
-        const fe* src0 = (!live0 || cw0.y == WIRE_CONST) ? a.coeff + 1 : a.W + (size_t)cw0.y * batch + p;
-        const fe* src1 = (!live1 || cw1.y == WIRE_CONST) ? a.coeff + 1 : a.W + (size_t)cw1.y * batch + p;
-        const fe cf0 = load_fe(a.coeff + cid0), x0 = load_fe(src0);
-        fe prod0, prod1 = Fr::zero();
-        if (two) {
-            const fe cf1 = load_fe(a.coeff + cid1), x1 = load_fe(src1);
-            prod0 = few_term(cf0, x0, cid0);
-            prod1 = few_term(cf1, x1, cid1);
-        } else prod0 = few_term(cf0, x0, cid0);
-        if (stamps && lane == 0) stamps[6] = wall_clock64() + (prod0.l[0] & prod1.l[0] & 0u);
+    for (uint32_t t0 = 0; t0 < T; t0 += CHUNK) {
+        const uint32_t nslot = T - t0 > CHUNK ? (uint32_t)FEW_SLOTS : (T - t0 + 63) / 64;       // wave-uniform: most ops have a handful of terms
+        // coefficient x wire value, one term per (lane, slot).  Nearly every wire of these circuits is a bit and most coefficients
+        // are +-1: such a product is a select; the terms that need the 353-instruction Montgomery multiplication are queued per lane
+        fe cf[FEW_SLOTS], x[FEW_SLOTS], prod[FEW_SLOTS];
+        uint32_t cid[FEW_SLOTS];
+#pragma unroll
+        for (int j = 0; j < FEW_SLOTS; j++) {
+            if ((uint32_t)j < nslot) {
+                const uint2 cw = t0 ? terms[t0 + 64 * j + lane] : f.cw[j];
+                const bool live = t0 + 64 * j + lane < T;
+                // a dead lane multiplies coefficient 0 (the constant 0) by coefficient 1 (the constant 1): ids checked at InitAlgorithm
+                cid[j] = live ? cw.x : 0u;
+                const bool cst = !live || cw.y == WIRE_CONST;
+                cf[j] = load_fe(a.coeff + cid[j]);
+                x[j] = load_wire(cst ? a.coeff + 1 : a.W + (size_t)cw.y * batch + p, dev);       // one branch-free load: no early wait
+            }
+        }
+        uint32_t hard = 0;
+#pragma unroll
+        for (int j = 0; j < FEW_SLOTS; j++) {
+            prod[j] = Fr::zero();
+            if ((uint32_t)j < nslot) {
+                const bool z = Fr::is_zero(x[j]), o = Fr::eq(x[j], Fr::one());
+                const fe nx = Fr::neg(x[j]);
+#pragma unroll
+                for (int k = 0; k < 8; k++) prod[j].l[k] = z ? 0u : o ? cf[j].l[k] : cid[j] == 1 ? x[j].l[k] : nx.l[k];
+                if (!(z || o || cid[j] == 1 || cid[j] == 3)) hard |= 1u << j;
+            }
+        }
+#pragma unroll 1
+        while (__builtin_amdgcn_ballot_w64(hard != 0) != 0) {          // usually not at all, else once
+            const uint32_t j = hard ? (uint32_t)__builtin_ctz(hard) : 0u;
+            const fe m = Fr::mul(pick_slot(cf, j), pick_slot(x, j));
+#pragma unroll
+            for (int q = 0; q < FEW_SLOTS; q++) {
+                const bool take = hard != 0 && j == (uint32_t)q;
+#pragma unroll
+                for (int k = 0; k < 8; k++) prod[q].l[k] = take ? m.l[k] : prod[q].l[k];
+            }
+            hard &= hard - 1;
+        }
+        if (stamps && lane == 0) stamps[6] = wall_clock64() + (prod[0].l[0] & prod[FEW_SLOTS - 1].l[0] & 0u);
 #pragma unroll 1
         for (uint32_t e = 0; e < 3; e++) {
             const uint32_t s = e == 0 ? 0u : e == 1 ? n0 : n0 + n1, n = e == 0 ? n0 : e == 1 ? n1 : n2;
-            // the expression's terms inside this chunk: [lo, hi) relative to t0, of which [lo, mid) sit in the first 64 lanes' slot
-            const uint32_t lo = s > t0 ? s - t0 : 0u, hi = s + n > t0 ? (s + n - t0 < 128u ? s + n - t0 : 128u) : 0u;
+            // the expression's terms inside this chunk: [lo, hi) relative to t0
+            const uint32_t lo = s > t0 ? s - t0 : 0u, hi = s + n > t0 ? (s + n - t0 < CHUNK ? s + n - t0 : CHUNK) : 0u;
             if (hi <= lo) continue;
             fe sum;
             if (hi - lo <= 6) {
-                sum = lo < 64 ? readlane_fe(prod0, lo) : readlane_fe(prod1, lo - 64);
-                for (uint32_t k = lo + 1; k < hi; k++) sum = Fr::add(sum, k < 64 ? readlane_fe(prod0, k) : readlane_fe(prod1, k - 64));
+                sum = readlane_fe(pick_slot(prod, lo >> 6), lo & 63);
+                for (uint32_t k = lo + 1; k < hi; k++) sum = Fr::add(sum, readlane_fe(pick_slot(prod, k >> 6), k & 63));
             } else {
-                const bool in0 = lane >= lo && lane < hi, in1 = lane + 64 >= lo && lane + 64 < hi;
-                fe s0, s1;
+                sum = Fr::zero();
 #pragma unroll
-                for (int k = 0; k < 8; k++) { s0.l[k] = in0 ? prod0.l[k] : 0u; s1.l[k] = in1 ? prod1.l[k] : 0u; }
-                sum = few_wave_sum(hi > 64 ? Fr::add(s0, s1) : s0);
+                for (int j = 0; j < FEW_SLOTS; j++) {
+                    if (hi > 64u * j && lo < 64u * (j + 1)) {            // wave-uniform
+                        const bool in = lane + 64u * j >= lo && lane + 64u * j < hi;
+                        fe t;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) t.l[k] = in ? prod[j].l[k] : 0u;
+                        sum = Fr::add(sum, t);
+                    }
+                }
+                sum = few_wave_sum(sum);
             }
             if (e == 0) va = Fr::add(va, sum); else if (e == 1) vb = Fr::add(vb, sum); else vc = Fr::add(vc, sum);
         }
@@ -384,6 +437,7 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
                 for (int k = 0; k < 8; k++) ab.l[k] = a1 ? vb.l[k] : 0u;
             } else ab = Fr::mul(va, vb);
         }
+        if (stamps && lane == 0) stamps[8] = wall_clock64() + (ab.l[0] & 0u);
         if (loc == 0) bad = !Fr::eq(ab, vc);
         else {
             fe wire;
@@ -398,25 +452,29 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
             }
             if (uc == 3) wire = Fr::neg(wire);
             else if (uc != 1) wire = Fr::mul(wire, load_fe(a.coeff_inv + uc));
-            if (mine) store_fe(a.W + (size_t)uw * batch + lane, wire);
+            if (stamps && lane == 0) stamps[9] = wall_clock64() + (wire.l[0] & 0u);
+            if (lane == 0) store_wire(a.W + (size_t)uw * batch + p, wire, a.coherent != 0);
         }
-        if (mine) {
-            store_fe(a.A + (size_t)cidx * batch + lane, va);
-            store_fe(a.B + (size_t)cidx * batch + lane, vb);
-            store_fe(a.C + (size_t)cidx * batch + lane, vc);
+        {       // one store instruction for the three rows: lanes 0..2
+            fe out;
+#pragma unroll
+            for (int k = 0; k < 8; k++) out.l[k] = lane == 0 ? va.l[k] : lane == 1 ? vb.l[k] : vc.l[k];
+            fe* row = lane == 0 ? a.A : lane == 1 ? a.B : a.C;
+            if (lane < 3) store_fe(row + (size_t)cidx * batch + p, out);
         }
+        if (stamps && lane == 0) stamps[10] = wall_clock64();
     } else if (op == OP_NBITS) {
+        if (stamps && lane == 0) stamps[11] = wall_clock64();
         const fe r = Fr::from_mont(va);
         const fe one = Fr::one();
-        uint32_t limb = 0;
 #pragma unroll 1
-        for (uint32_t k = 0; k < w2; k++) {
-            if ((k & 31) == 0) limb = k < 256 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)limb_at(r, k >> 5)) : 0u;
-            const bool bit = (limb >> (k & 31)) & 1u;
+        for (uint32_t k0 = 0; k0 < w2; k0 += 64) {                   // lane k: bit k0 + k
+            const uint32_t k = k0 + lane;
+            const bool bit = k < 256 && ((limb_at(r, (k >> 5) & 7) >> (k & 31)) & 1u);
             fe v;
 #pragma unroll
             for (int j = 0; j < 8; j++) v.l[j] = bit ? one.l[j] : 0u;
-            if (mine) store_fe(a.W + (size_t)(w1 + k) * batch + lane, v);
+            if (k < w2) store_wire(a.W + (size_t)(w1 + k) * batch + p, v, a.coherent != 0);
         }
     } else if (op == OP_LOOKUP) {
         const fe r = Fr::from_mont(va);
@@ -424,12 +482,12 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
         if (hi != 0 || r.l[0] >= 256) bad = true;
         const uint32_t cid = a.lookup_coeff[w2 * 256 + (r.l[0] & 255)];
         const fe v = load_fe(a.coeff + cid);
-        if (mine) store_fe(a.W + (size_t)w1 * batch + lane, v);
+        if (lane == 0) store_wire(a.W + (size_t)w1 * batch + p, v, a.coherent != 0);
     } else if (op == OP_RANDOMIZE || op == OP_COMMIT) {
         const fe* src = op == OP_RANDOMIZE ? a.mask : a.commit;
         const fe v = src ? load_fe(src + p) : Fr::zero();
 #pragma unroll 1
-        for (uint32_t k = 0; k < w2; k++) if (mine) store_fe(a.W + (size_t)(w1 + k) * batch + lane, v);
+        for (uint32_t k = lane; k < w2; k += 64) store_wire(a.W + (size_t)(w1 + k) * batch + p, v, a.coherent != 0);
     }
     if (bad && lane == 0) atomicMin(a.status + p, i);
 }
@@ -438,26 +496,27 @@ template <bool HAS_DIV>
 __global__ __launch_bounds__(64 * FEW_WAVES) void k_solver_few(SolverFewArgs a) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t gw = wave * gridDim.x + blockIdx.x, nw = gridDim.x * FEW_WAVES;       // neighbouring items (the long ops come first) go to different CUs
-    const uint32_t lane_mod = lane % a.n_real;
     uint32_t epoch = 0;
     auto op_of = [&](uint32_t l0, uint32_t it) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(l0 + it / a.n_real)); };
     uint32_t l0 = a.level_start[a.from], l1 = a.level_start[a.from + 1];
     FewFetch f = few_fetch(a, op_of(l0, gw < (l1 - l0) * a.n_real ? gw : 0u), lane);       // (a wave without an item fetches op 0: harmless)
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) { a.trace[16 * a.nlev_trace + 0] = wall_clock64(); a.trace[16 * a.nlev_trace + 1] = clock64(); }
     for (uint32_t lev = a.from; lev < a.to; lev++) {
         const uint32_t items = (l1 - l0) * a.n_real;
-        unsigned long long* stamps = a.trace && blockIdx.x == 0 ? a.trace + 8 * lev : nullptr;       // workgroup 0 only: it holds the level's first (longest) op
+        unsigned long long* stamps = a.trace && blockIdx.x == 0 ? a.trace + 16 * lev : nullptr;       // workgroup 0 only: it holds the level's first (longest) op
         if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();
         for (uint32_t it = gw; it < items; it += nw) {
             const uint32_t i = op_of(l0, it);
             const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(it % a.n_real));
             if (it != gw) f = few_fetch(a, i, lane);
-            few_item<HAS_DIV>(a, f, i, p, lane, lane_mod == p, it == 0 ? stamps : nullptr);
+            few_item<HAS_DIV>(a, f, i, p, lane, it == 0 ? stamps : nullptr);
         }
         if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
-        if (lev + 1 == a.to) break;
+        if (a.trace && lane == 0 && gw < items) atomicMax(a.trace + 16 * lev + 12, wall_clock64());
+        if (lev + 1 == a.to) { if (stamps && threadIdx.x == 0) { a.trace[16 * a.nlev_trace + 2] = wall_clock64(); a.trace[16 * a.nlev_trace + 3] = clock64(); } break; }
         l0 = l1; l1 = a.level_start[lev + 2];
         f = few_fetch(a, op_of(l0, gw < (l1 - l0) * a.n_real ? gw : 0u), lane);            // static data of the next level's item: in flight across the barrier
-        if (!few_grid_barrier(a.sync, ++epoch * gridDim.x, stamps)) {
+        if (!few_grid_barrier(a.sync, ++epoch * gridDim.x, stamps, a.coherent != 0)) {
             if (threadIdx.x < a.n_real && blockIdx.x == 0) atomicMin(a.status + threadIdx.x, 0u);      // reported as unsatisfied
             return;
         }
@@ -606,8 +665,16 @@ void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint
 }
 void launch_solver_few(const SolverFewArgs& a, int has_div, uint32_t workgroups, hipStream_t s) {
     if (a.from >= a.to) return;
-    if (has_div) hipLaunchKernelGGL(k_solver_few<true>, dim3(workgroups), dim3(64 * FEW_WAVES), 0, s, a);
-    else hipLaunchKernelGGL(k_solver_few<false>, dim3(workgroups), dim3(64 * FEW_WAVES), 0, s, a);
+    // 96 KiB of (unused) dynamic LDS: more than half of a CU's 160 KiB, so that no two workgroups share a CU and every wave has a
+    // SIMD nearly to itself — the level time is the longest op's serial instruction stream
+    constexpr size_t lds = 96 * 1024;
+    static const bool attr = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_solver_few<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(k_solver_few<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    }();
+    const size_t dyn = attr ? lds : 0;
+    if (has_div) hipLaunchKernelGGL(k_solver_few<true>, dim3(workgroups), dim3(64 * FEW_WAVES), dyn, s, a);
+    else hipLaunchKernelGGL(k_solver_few<false>, dim3(workgroups), dim3(64 * FEW_WAVES), dyn, s, a);
 }
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
     if (!level_width) return;

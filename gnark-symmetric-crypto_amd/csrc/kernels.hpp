@@ -66,6 +66,8 @@ struct SolverFewArgs {
     fe* W; fe* A; fe* B; fe* C; size_t batch; uint32_t n_real;
     uint32_t* status; const fe* mask; const fe* commit;
     uint32_t* sync;
+    uint32_t coherent;                              // 1: wire values move with device-scope accesses, the barrier does no cache maintenance (k_solver.hip load_wire)
+    uint32_t nlev_trace;                            // diagnostics: slot of the whole-launch stamps in trace (the program's level count)
     unsigned long long* trace;                      // diagnostics (GSC_SOLVER_TRACE): per level stamps of workgroup 0 (100 MHz clock: level in, first item done, workgroup done, released, all arrived, acquired), or nullptr
 };
 void launch_solver_few(const SolverFewArgs& a, int has_div, uint32_t workgroups, hipStream_t s);
@@ -169,8 +171,11 @@ struct MsmFlatRecodeArgs {
     size_t nbases, batch; int c;
     uint4* digits;
     size_t nbit; const uint8_t* group_ok; uint8_t* gok;
+    int mont;                                       // scalars are Montgomery values (wires) or canonical integers (h)
 };
 void launch_msm_recode_flat(const MsmFlatRecodeArgs& a, hipStream_t s);
+// lanes = octets of one proof; gok[octet * MSM_FEW_PROOFS + proof]; pairs with launch_msm_flat_few_* (nslices = ceil(octets / 64))
+void launch_msm_recode_flat_few(const MsmFlatRecodeArgs& a, size_t nproofs, hipStream_t s);
 // partial[slice * batch + p]; one wave per (slice of `per` consecutive bases, 64 proofs); per a multiple of 8, at most 512
 struct MsmFlatArgs {
     const void* table; const uint64_t* rowoff; const uint32_t* rowlen; size_t nbases;
@@ -182,6 +187,8 @@ struct MsmFlatArgs {
 };
 void launch_msm_flat_g1(const MsmFlatArgs& a, hipStream_t s);
 void launch_msm_flat_g2(const MsmFlatArgs& a, hipStream_t s);
+void launch_msm_flat_few_g1(const MsmFlatArgs& a, size_t nproofs, hipStream_t s);
+void launch_msm_flat_few_g2(const MsmFlatArgs& a, size_t nproofs, hipStream_t s);
 
 // One reduction level over slices: out[g][column] = sum of the partials of group g of slices; returns the number of groups (1 = out
 // is the final sum).  `batch` counts independent columns (proofs, or windows x proofs).  Groups hold 64 slices (butterfly over
