@@ -84,6 +84,7 @@ EngineConfig config_from_env() {
     c.few_solver = env_int("GSC_FEW_SOLVER", 1);
     c.few_workgroups = env_int("GSC_FEW_WGS", 64);
     c.few_coherent = env_int("GSC_FEW_COHERENT", 1);
+    c.few_z_gb = env_int("GSC_FEW_Z_GB", 12);
     if (c.few_workgroups < 1 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [1, 256]");
     c.win_slice = (size_t)env_int("GSC_WIN_SLICE", 256);
     if (c.win_slice < 8 || c.win_slice > 4096) throw std::runtime_error("GSC_WIN_SLICE must be in [8, 4096]");
@@ -120,7 +121,7 @@ class AlgorithmImpl {
     // NTT
     DevBuf<int32_t> tw_fwd, tw_inv, qr; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n
     // MSM sets
-    MsmSet<G1Aff> mA, mB1, mK, mZ, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
+    MsmSet<G1Aff> mA, mB1, mK, mZ, mZfew, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
     // batch buffers: one set per lane.  A lane = a HIP stream with its own witness / polynomial / partial-sum buffers; with more than
     // one lane big batches are cut into chunks that the lanes prove concurrently.  Measured on MI355X: two lanes do
     // NOT beat one lane with the same number of proofs in flight (the MSM kernels already fill the chip and two of them thrash
@@ -136,10 +137,11 @@ class AlgorithmImpl {
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
+        DevBuf<uint4> d_digits_s; DevBuf<uint8_t> d_gok_s; DevBuf<G1Xyzz> d_part1c, d_part1d;      // the side stream's MSM scratch (A and B1 of a latency-path call)
         DevBuf<uint4> d_digits;                                                   // signed digits [window][octet][proof]
         // per-window sums [window][proof] and flat-part sums [proof], one pair per set: the Horner passes of several sets are deferred
         // and run as one launch (MsmHornerJobs), so their inputs must not share storage
-        static constexpr int NSETS = 6;      // A, B1, K, Z, Ped, PedSigma
+        static constexpr int NSETS = 7;      // A, B1, K, Z, Ped, PedSigma, Z (latency layout)
         DevBuf<G1Xyzz> d_sj1[NSETS], d_flat1[NSETS]; DevBuf<G2Xyzz> d_sj2, d_flat2;
         MsmHornerJobs pending1{}, pending2{};
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
@@ -323,7 +325,7 @@ class AlgorithmImpl {
     // NARROW_MAX_BITS bits (with the margin) -> flat rows of that length; the rest (r, s, the lookup argument's products and inverses)
     // are wide: a few of them become window octets of the flat part, many get the windowed kernel and a Horner pass.
     template <class AffT, class XyzzT, class Decomp>
-    void build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw, size_t point_bytes, const std::vector<uint32_t>& rows, int c, const char* what, Decomp decomp, bool uniform) {
+    void build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw, size_t point_bytes, const std::vector<uint32_t>& rows, int c, const char* what, Decomp decomp, bool uniform, int expand_cv = 0) {
         const size_t n = raw.size() / point_bytes;
         if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
         set.nbases = n; set.c = c; set.nwin = msm_windows(c);
@@ -341,7 +343,8 @@ class AlgorithmImpl {
             else if (k <= 1) bits.push_back((uint32_t)i);
             else { narrow.push_back((uint32_t)i); const int lb = k + cfg.row_margin_bits; narrow_len.push_back(1u << (lb < 0 ? 0 : lb)); }
         }
-        if (!uniform) {
+        // expand_cv > 0: EVERY base becomes window octets of that digit width (the latency-path layout of the quotient bases: no Horner pass)
+        if (!uniform || expand_cv > 0) {
             while (bits.size() % 8) { narrow.insert(narrow.begin(), bits.back()); narrow_len.insert(narrow_len.begin(), 2u); bits.pop_back(); }
             // flat part: [bits][narrow][padding to an octet][window octets of the expanded wide wires]
             std::vector<uint32_t> src(bits), shift, frows, len; std::vector<int32_t> octwin;
@@ -350,9 +353,9 @@ class AlgorithmImpl {
             len.assign(bits.size(), 1u); len.insert(len.end(), narrow_len.begin(), narrow_len.end());
             while (src.size() % 8) { src.push_back(src.empty() ? 0u : src[0]); frows.push_back(ROW_ZERO); len.push_back(1u); }
             shift.assign(src.size(), 0u); octwin.assign(src.size() / 8, -1);
-            const bool expand = !wide.empty() && wide.size() <= EXPAND_MAX && n > 0;
+            const bool expand = !wide.empty() && (expand_cv > 0 || wide.size() <= EXPAND_MAX) && n > 0;
             if (expand) {
-                set.cv = EXPAND_C; const int nwv = msm_windows(set.cv), octs = (nwv + 7) / 8;
+                set.cv = expand_cv > 0 ? expand_cv : EXPAND_C; const int nwv = msm_windows(set.cv), octs = (nwv + 7) / 8;
                 for (uint32_t w : wide) for (int q = 0; q < 8 * octs; q++) {
                     src.push_back(w); frows.push_back(rows[w]); shift.push_back(q < nwv ? (uint32_t)(set.cv * q) : 0u); len.push_back(q < nwv ? 1u << (set.cv - 1) : 1u);
                     if (q % 8 == 0) octwin.push_back(q);
@@ -473,6 +476,14 @@ class AlgorithmImpl {
         timed("G1.B", [&] { build_set<G1Aff, G1Xyzz>(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, false); });
         timed("G1.K", [&] { build_set<G1Aff, G1Xyzz>(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, false); });
         timed("G1.Z", [&] { build_set<G1Aff, G1Xyzz>(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, true); });      // uniform full-width scalars
+        if (cfg.few_path && cfg.few_z_gb > 0) {
+            // calls with a handful of statements: the quotient bases once more as (base, window) pairs with their own rows 2^(cv j) d P — more
+            // additions per proof than the wide rows above, but no 254-doubling Horner chain behind them (1.4 ms of a 6 ms Prove)
+            const size_t nz = key.g1_Z.size() / 32;
+            int cv = 0;
+            for (int t : {8, 6, 4}) if ((double)nz * msm_windows(t) * (double)((size_t)1 << (t - 1)) * sizeof(G1Aff) <= (double)cfg.few_z_gb * 1e9) { cv = t; break; }
+            if (cv) timed("G1.Z (latency layout)", [&] { build_set<G1Aff, G1Xyzz>(mZfew, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, true, cv); });
+        }
         timed("G2.B", [&] { build_set<G2Aff, G2Xyzz>(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, false); });
         if (cs.has_commitment) {
             if (cs.n_public_committed) throw std::runtime_error("r1cs: public committed wires are not supported");
@@ -494,7 +505,7 @@ class AlgorithmImpl {
         HIP_CHECK(hipMemsetAsync(ln.d_W.p, 0, ln.d_W.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_A.p, 0, ln.d_A.n * sizeof(fe), ln.stream));
         HIP_CHECK(hipMemsetAsync(ln.d_B.p, 0, ln.d_B.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_C.p, 0, ln.d_C.n * sizeof(fe), ln.stream));
         // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
-        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0};
+        size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0, 0};
         auto need = [&](auto& m, size_t b, size_t& pa, size_t& pb, size_t& sj) {
             auto part = [&](size_t nb, size_t ns, size_t cols) {
                 if (ns * cols > pa) pa = ns * cols;
@@ -504,13 +515,23 @@ class AlgorithmImpl {
             if (m.nflat) { part(m.nflat, msm_slices(m.nflat, 1, 256, b, per), b); if (m.nflat / 8 * b > dg) dg = m.nflat / 8 * b; if (m.nbit / 8 * (b / 64) > gk) gk = m.nbit / 8 * (b / 64); if (m.nbit / 8 * MSM_FEW_PROOFS > gk) gk = m.nbit / 8 * MSM_FEW_PROOFS; }
             if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, cfg.win_slice, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
         };
-        MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma};
+        MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew};
         for (size_t b = 64; b <= B; b += 64) {
-            for (int k = 0; k < Lane::NSETS; k++) need(*g1sets[k], b, p1, p1b, sj1[k]);
+            for (int k = 0; k < Lane::NSETS; k++) if (g1sets[k] != &mZfew || b == 64) need(*g1sets[k], b, p1, p1b, sj1[k]);      // the latency layout only serves 64-column batches
             need(mB2, b, p2, p2b, sj2);
         }
         ln.d_part1a.alloc(p1); ln.d_part1b.alloc(p1b); ln.d_part2a.alloc(p2); ln.d_part2b.alloc(p2b);
         ln.d_digits.alloc(dg); ln.d_gok.alloc(gk ? gk : 1);
+        {
+            size_t dgs = 1, gks = 1, ps = 1;
+            for (const MsmSet<G1Aff>* m : {&mA, &mB1}) {
+                const size_t noct = (m->nflat + 7) / 8, nsl = (noct + 63) / 64;
+                if (noct * 64 > dgs) dgs = noct * 64;
+                if (m->nbit / 8 * MSM_FEW_PROOFS > gks) gks = m->nbit / 8 * MSM_FEW_PROOFS;
+                if (nsl * 64 > ps) ps = nsl * 64;
+            }
+            ln.d_digits_s.alloc(dgs); ln.d_gok_s.alloc(gks); ln.d_part1c.alloc(ps); ln.d_part1d.alloc((ps / 64 + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * 64 + 64);
+        }
         for (int k = 0; k < Lane::NSETS; k++) { ln.d_sj1[k].alloc(sj1[k] ? sj1[k] : 1); ln.d_flat1[k].alloc(g1sets[k]->nflat && g1sets[k]->nwide ? B : 1); }
         ln.d_sj2.alloc(sj2 ? sj2 : 1); ln.d_flat2.alloc(B);
         ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
@@ -529,13 +550,14 @@ class AlgorithmImpl {
         return n ? n : 1;
     }
     bool few_solver_wanted(size_t n, size_t B) const { return n <= MSM_FEW_PROOFS && B == 64 && cfg.few_solver; }
+    struct MsmCtx { hipStream_t stream; uint4* digits; uint8_t* gok; };
     template <class XyzzT, class LR>
-    void reduce_slices(Lane& ln, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, XyzzT* out, LR launch_reduce) {
+    void reduce_slices(hipStream_t st, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, XyzzT* out, LR launch_reduce) {
         XyzzT* src = pa; XyzzT* alt = pb; size_t ns = nslices;
         for (;;) {
             const size_t groups = msm_reduce_groups(ns, cols);
             XyzzT* dst = groups == 1 ? out : alt;
-            launch_reduce(src, ns, cols, dst, ln.stream);
+            launch_reduce(src, ns, cols, dst, st);
             if (groups == 1) break;
             XyzzT* t = src; src = dst; alt = t; ns = groups;
         }
@@ -544,24 +566,26 @@ class AlgorithmImpl {
     // The Horner pass of the windowed part is NOT launched here: it is queued in `pending` and flushed together with those of other
     // sets (flush_horner_*), because each is a serial chain of 254 doublings whose duration does not depend on the batch.
     template <class AffT, class XyzzT, class LF, class LFF, class LW, class LWF, class LR>
-    void run_msm(Lane& ln, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
+    void run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
                  MsmHornerJobs& pending, LF launch_flat, LFF launch_flat_few, LW launch_win, LWF launch_win_few, LR launch_reduce) {
         size_t per = 0;
         if (set.nflat) {
-            MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ln.d_digits.p, set.nbit, set.group_ok.p, ln.d_gok.p, wires ? 1 : 0};
+            MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ctx.digits, set.nbit, set.group_ok.p, ctx.gok, wires ? 1 : 0};
             if (n_real <= MSM_FEW_PROOFS && cfg.few_path) {       // a single Prove call: lanes = octets of bases (columns of the padding proofs: the point at infinity)
                 const size_t nslices = ((set.nflat + 7) / 8 + 63) / 64;
-                launch_msm_recode_flat_few(ra, n_real, ln.stream);
-                HIP_CHECK(hipMemsetAsync(pa, 0, nslices * B * sizeof(XyzzT), ln.stream));
-                MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ln.d_digits.p, B, nslices, 512, pa, set.nbit, set.sub.p, ln.d_gok.p, scalars, set.frows.p};
-                launch_flat_few(a, n_real, ln.stream);
-                reduce_slices(ln, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
+                launch_msm_recode_flat_few(ra, n_real, ctx.stream);
+                HIP_CHECK(hipMemsetAsync(pa, 0, nslices * B * sizeof(XyzzT), ctx.stream));
+                MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ctx.digits, B, nslices, 512, pa, set.nbit, set.sub.p, ctx.gok, scalars, set.frows.p};
+                if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
+                launch_flat_few(a, n_real, ctx.stream);
+                if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ctx.stream));
+                reduce_slices(ctx.stream, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
             } else {
                 const size_t nslices = msm_slices(set.nflat, 1, 256, B, per);
-                launch_msm_recode_flat(ra, ln.stream);
-                MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ln.d_digits.p, B, nslices, per, pa, set.nbit, set.sub.p, ln.d_gok.p, scalars, set.frows.p};
-                launch_flat(a, ln.stream);
-                reduce_slices(ln, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
+                launch_msm_recode_flat(ra, ctx.stream);
+                MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ctx.digits, B, nslices, per, pa, set.nbit, set.sub.p, ctx.gok, scalars, set.frows.p};
+                launch_flat(a, ctx.stream);
+                reduce_slices(ctx.stream, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
             }
         }
         if (set.nwide) {
@@ -571,29 +595,36 @@ class AlgorithmImpl {
             size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, cfg.win_slice, B, per);
             if (few && nslices > (set.nwide + 511) / 512) { per = 512; nslices = (set.nwide + 511) / 512; }
             const size_t Bw = B * (size_t)set.nwin;
-            MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ln.d_digits.p};
-            launch_msm_recode(ra, ln.stream);
-            MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ln.d_digits.p, B, nslices, per, pa, cfg.msm_placement, 0};
+            MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ctx.digits};
+            launch_msm_recode(ra, ctx.stream);
+            MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa, cfg.msm_placement, 0};
             if (const char* e = getenv("GSC_MSM_EXP")) { if (getenv("GSC_ENABLE_TEST_HOOKS") && (atoi(e) & 1)) a.exp_same_entry = 1; if (atoi(e) & 2) a.placement = 1; if (atoi(e) & 4) a.placement = 0; }
-            if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));
+            if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
             if (few) {      // columns of the padding proofs: the point at infinity
-                HIP_CHECK(hipMemsetAsync(pa, 0, nslices * Bw * sizeof(XyzzT), ln.stream));
-                launch_win_few(a, n_real, ln.stream);
-            } else launch_win(a, ln.stream);
-            if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
-            reduce_slices(ln, pa, pb, nslices, Bw, sj, launch_reduce);      // slices -> one sum per (window, proof)
+                HIP_CHECK(hipMemsetAsync(pa, 0, nslices * Bw * sizeof(XyzzT), ctx.stream));
+                launch_win_few(a, n_real, ctx.stream);
+            } else launch_win(a, ctx.stream);
+            if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ctx.stream));
+            reduce_slices(ctx.stream, pa, pb, nslices, Bw, sj, launch_reduce);      // slices -> one sum per (window, proof)
             if (pending.n >= MSM_HORNER_JOBS) throw std::runtime_error("internal: too many pending Horner passes");
             pending.job[pending.n++] = MsmHornerJob{sj, set.nflat ? flat : (XyzzT*)nullptr, sum, set.nwin, set.c};
         }
-        if (!set.nflat && !set.nwide) HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ln.stream));      // empty set: the point at infinity
+        if (!set.nflat && !set.nwide) HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ctx.stream));      // empty set: the point at infinity
     }
-    int set_index(const MsmSet<G1Aff>& set) const { const MsmSet<G1Aff>* all[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma}; for (int k = 0; k < Lane::NSETS; k++) if (all[k] == &set) return k; return 0; }
-    void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false) {
+    int set_index(const MsmSet<G1Aff>& set) const { const MsmSet<G1Aff>* all[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew}; for (int k = 0; k < Lane::NSETS; k++) if (all[k] == &set) return k; return 0; }
+    // side = true: on the lane's side stream with scratch buffers of its own (flat sets of calls with a handful of statements only)
+    void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false, bool side = false) {
         const int k = set_index(set);
-        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
+        if (side) {
+            if (set.nwide || B != 64) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
+            run_msm(ln, MsmCtx{ln.side, ln.d_digits_s.p, ln.d_gok_s.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1c.p, ln.d_part1d.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, false, ln.pending1,
+                    launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
+            return;
+        }
+        run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
     }
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
-        run_msm(ln, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2);
+        run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2);
     }
     void flush_horner_g1(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g1(ln.pending1, B, s); ln.pending1.n = 0; }
     void flush_horner_g2(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g2(ln.pending2, B, s); ln.pending2.n = 0; }
@@ -682,20 +713,32 @@ class AlgorithmImpl {
             fetch_column(ln, ln.d_W.p, n_wires, B, 0, dbg->W); fetch_column(ln, ln.d_A.p, n_constraints, B, 0, dbg->A);
             fetch_column(ln, ln.d_B.p, n_constraints, B, 0, dbg->B); fetch_column(ln, ln.d_C.p, n_constraints, B, 0, dbg->C);
         }
+        // A latency-path call leaves the chip mostly idle, so its A and B1 sums and the two scalar multiplications that need them (s * Ar,
+        // r * Bs1: 254 serial doublings, 2 ms) start on the side stream right after the witness, beside the quotient and the other MSMs.
+        const bool early_ab = ln.n_real <= MSM_FEW_PROOFS && cfg.few_path && B == 64 && !mA.nwide && !mB1.nwide;
+        if (early_ab) {
+            HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
+            HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
+            run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p, false, true);
+            run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p, false, true);
+            launch_fin_scalarmul(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
+        }
         // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
         NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
         HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
         HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream));
         HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
         if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
-        // 3. MSMs.  A and B1 first: the two scalar multiplications of the assembly (s * Ar, r * Bs1: 254 serial doublings) only need
-        // those two sums and run on a side stream beside the remaining MSMs.
-        run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p);
-        run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p);
-        flush_horner_g1(ln, B, ln.stream);                                           // (AES-V2: the wide wires of A and B1; nothing for ChaCha20-V3)
-        HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
-        HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
-        launch_fin_scalarmul(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
+        // 3. MSMs.  A and B1 first: the two scalar multiplications of the assembly only need those two sums and run on a side stream
+        // beside the remaining MSMs.
+        if (!early_ab) {
+            run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p);
+            run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p);
+            flush_horner_g1(ln, B, ln.stream);                                       // (AES-V2: the wide wires of A and B1; nothing for ChaCha20-V3)
+            HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
+            HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
+            launch_fin_scalarmul(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
+        }
         run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p);
         if (ln.pending2.n) {                                                         // the G2 Horner chain (3x a G1 one) also goes beside the MSMs
             HIP_CHECK(hipEventRecord(ln.ev_b2, ln.stream));
@@ -704,7 +747,7 @@ class AlgorithmImpl {
         }
         HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
         run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
-        run_msm_g1(ln, mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, true);
+        run_msm_g1(ln, ln.n_real <= MSM_FEW_PROOFS && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, true);
         if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
         flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
         if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);

@@ -42,6 +42,7 @@ struct EngineConfig {
     int few_path = 1;            // GSC_FEW_PATH: calls with at most 8 statements use the lanes-are-bases MSM kernel (latency path); 0 = always the batch kernel
     int few_solver = 1;          // GSC_FEW_SOLVER: such calls also solve the witness with the resident lanes-are-terms kernel (k_solver_few); 0 = one launch per level
     int few_workgroups = 64;     // GSC_FEW_WGS: its grid (workgroups of 8 waves, one per CU; far fewer than the chip holds, so all are resident)
+    int few_z_gb = 12;           // GSC_FEW_Z_GB: HBM budget of the latency-path layout of the quotient bases (rows per (base, window) of 8-, 6- or 4-bit digits: 8.6 GB ChaCha20 at 8, 11.5 GB AES at 6); 0 = none, such calls run the Horner pass
     int few_coherent = 1;        // GSC_FEW_COHERENT: 1 wire values cross workgroups through device-scope accesses; 0 plain accesses + L2 write-back / invalidate at every barrier
     int msm_placement = 0;       // GSC_MSM_PLACEMENT: workgroup placement of the MSM kernel (kernels.hpp MsmWinArgs::placement)
 };

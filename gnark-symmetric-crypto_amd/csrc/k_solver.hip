@@ -394,18 +394,23 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
             hard &= hard - 1;
         }
         if (stamps && lane == 0) stamps[6] = wall_clock64() + (prod[0].l[0] & prod[FEW_SLOTS - 1].l[0] & 0u);
-#pragma unroll 1
-        for (uint32_t e = 0; e < 3; e++) {
+        // per expression: a handful of terms are read lane by lane; more are masked into a per-lane value and folded by a butterfly —
+        // the butterflies of L and O (ChaCha20's add32 rows: 96 and 33 terms) run as one loop, two independent chains interleaved
+        fe ls[3]; uint32_t longm = 0;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
             const uint32_t s = e == 0 ? 0u : e == 1 ? n0 : n0 + n1, n = e == 0 ? n0 : e == 1 ? n1 : n2;
             // the expression's terms inside this chunk: [lo, hi) relative to t0
             const uint32_t lo = s > t0 ? s - t0 : 0u, hi = s + n > t0 ? (s + n - t0 < CHUNK ? s + n - t0 : CHUNK) : 0u;
+            ls[e] = Fr::zero();
             if (hi <= lo) continue;
-            fe sum;
             if (hi - lo <= 6) {
-                sum = readlane_fe(pick_slot(prod, lo >> 6), lo & 63);
+                fe sum = readlane_fe(pick_slot(prod, lo >> 6), lo & 63);
+#pragma unroll 1
                 for (uint32_t k = lo + 1; k < hi; k++) sum = Fr::add(sum, readlane_fe(pick_slot(prod, k >> 6), k & 63));
+                if (e == 0) va = Fr::add(va, sum); else if (e == 1) vb = Fr::add(vb, sum); else vc = Fr::add(vc, sum);
             } else {
-                sum = Fr::zero();
+                longm |= 1u << e;
 #pragma unroll
                 for (int j = 0; j < FEW_SLOTS; j++) {
                     if (hi > 64u * j && lo < 64u * (j + 1)) {            // wave-uniform
@@ -413,13 +418,25 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
                         fe t;
 #pragma unroll
                         for (int k = 0; k < 8; k++) t.l[k] = in ? prod[j].l[k] : 0u;
-                        sum = Fr::add(sum, t);
+                        ls[e] = Fr::add(ls[e], t);
                     }
                 }
-                sum = few_wave_sum(sum);
             }
-            if (e == 0) va = Fr::add(va, sum); else if (e == 1) vb = Fr::add(vb, sum); else vc = Fr::add(vc, sum);
         }
+        if ((longm & 5u) == 5u) {
+#pragma unroll 1
+            for (int m = 32; m >= 1; m >>= 1) {
+                fe o0, o2;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { o0.l[k] = (uint32_t)__shfl_xor((int)ls[0].l[k], m); o2.l[k] = (uint32_t)__shfl_xor((int)ls[2].l[k], m); }
+                ls[0] = Fr::add(ls[0], o0); ls[2] = Fr::add(ls[2], o2);
+            }
+            va = Fr::add(va, ls[0]); vc = Fr::add(vc, ls[2]);
+            longm &= ~5u;
+        }
+        if (longm & 1u) va = Fr::add(va, few_wave_sum(ls[0]));
+        if (longm & 2u) vb = Fr::add(vb, few_wave_sum(ls[1]));
+        if (longm & 4u) vc = Fr::add(vc, few_wave_sum(ls[2]));
     }
     bool bad = false;
     if (stamps && lane == 0) stamps[7] = wall_clock64() + (va.l[0] & vb.l[0] & vc.l[0] & 0u);

@@ -195,7 +195,7 @@ assert g.init_algorithm(algo, pk, r1cs)
 assert "lanes=%s " % os.environ.get("GSC_LANES", "2" if algo else "1") in g.describe(algo), g.describe(algo)
 assert "devices=%d " % len(os.environ.get("GSC_DEVICES", "0").split(",")) in g.describe(algo), g.describe(algo)
 rnd = random.Random(4242)
-n = 333 if algo == 0 else 70
+n = int(os.environ.get("TEST_STATEMENTS", "333" if algo == 0 else "70"))
 keylen = 16 if algo == 1 else 32
 recs = b"".join(rnd.randbytes(keylen) + bytes(32 - keylen) + rnd.randbytes(12) + rnd.getrandbits(16).to_bytes(4, "little") + rnd.randbytes(64) for _ in range(n))
 g.set_deterministic_randomness(rnd.getrandbits(250), rnd.getrandbits(250), rnd.getrandbits(250))
@@ -209,7 +209,7 @@ def _digest(env_extra, algo=0, pk_path=None):
     import subprocess, sys
     from conftest import ROOT
     # small tables: these child processes share the device with the algorithms the test session already holds (~170 GB)
-    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8")
+    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_FEW_Z_GB="0")
     env.update(env_extra)
     args = [sys.executable, "-c", _OPTIONS_SCRIPT, ROOT, str(algo)] + ([pk_path] if pk_path else [])
     out = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900)
@@ -237,6 +237,20 @@ def test_engine_options_do_not_change_the_proofs_aes(aes_keys):
     base = _digest({}, 1, pk_path)
     for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_ROW_MARGIN_BITS": "-6"}):
         assert _digest(extra, 1, pk_path) == base, extra
+
+
+@pytest.mark.parametrize("algo,counts", [(0, ("1", "5")), (1, ("3",))])
+def test_latency_path_options_do_not_change_the_proofs(aes_keys, algo, counts):
+    # Calls with at most 8 statements take kernels of their own (resident lanes-are-terms solver with device-wide barriers, flat and
+    # windowed MSMs with lanes = bases, the quotient bases as (base, window) rows without a Horner pass, A / B1 sums early on the side
+    # stream).  With (r, s, mask) fixed, a handful of statements must give the same bytes as the batch kernels (GSC_FEW_PATH=0
+    # GSC_FEW_SOLVER=0), whatever the grid, the barrier's memory mode or the quotient layout.
+    from conftest import ROOT
+    pk_path = os.path.join(ROOT, "build", "keys", "pk.aes128") if algo else None
+    for n in counts:
+        base = _digest({"TEST_STATEMENTS": n, "GSC_FEW_PATH": "0", "GSC_FEW_SOLVER": "0"}, algo, pk_path)
+        for extra in ({"GSC_FEW_Z_GB": "12"}, {"GSC_FEW_Z_GB": "0"}, {"GSC_FEW_Z_GB": "12", "GSC_FEW_COHERENT": "0", "GSC_FEW_WGS": "17"}, {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": "3"}):
+            assert _digest(dict(extra, TEST_STATEMENTS=n), algo, pk_path) == base, (n, extra)
 
 
 def test_bench_size_batch_every_proof_verifies(gsc_chacha):
