@@ -82,10 +82,12 @@ EngineConfig config_from_env() {
     c.row_margin_bits = env_int("GSC_ROW_MARGIN_BITS", 1);
     c.few_path = env_int("GSC_FEW_PATH", 1);
     c.few_solver = env_int("GSC_FEW_SOLVER", 1);
-    c.few_workgroups = env_int("GSC_FEW_WGS", 64);
+    c.few_max = env_int("GSC_FEW_MAX", 32);
+    if (c.few_max < 1 || c.few_max > (int)MSM_FEW_PROOFS) throw std::runtime_error("GSC_FEW_MAX must be in [1, 32]");
+    c.few_workgroups = env_int("GSC_FEW_WGS", 0);
     c.few_coherent = env_int("GSC_FEW_COHERENT", 1);
     c.few_z_gb = env_int("GSC_FEW_Z_GB", 12);
-    if (c.few_workgroups < 1 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [1, 256]");
+    if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");
     c.win_slice = (size_t)env_int("GSC_WIN_SLICE", 256);
     if (c.win_slice < 8 || c.win_slice > 4096) throw std::runtime_error("GSC_WIN_SLICE must be in [8, 4096]");
     if (c.max_batch < 64) c.max_batch = 64;
@@ -93,6 +95,13 @@ EngineConfig config_from_env() {
     if ((c.window_z && (c.window_z < 4 || c.window_z > 16)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [4,16]");
     return c;
 }
+
+// The resident solver kernel (k_solver_few) spins at device-wide barriers, so two of them must never share the device: each could
+// hold CUs the other's missing workgroups are waiting for.  Launches are therefore chained on the device: a launch first makes its
+// stream wait for the previous one's completion event (no host blocking).  Other processes on the same device are not covered —
+// there the kernel's bounded polling gives up and the call is solved again with one launch per level (prove_chunk).
+struct FewSolverChain { std::mutex m; hipEvent_t last = nullptr; };
+static FewSolverChain& few_solver_chain(int device) { static FewSolverChain chains[64]; return chains[device & 63]; }
 
 class AlgorithmImpl {
   public:
@@ -129,6 +138,7 @@ class AlgorithmImpl {
     struct Lane {
         hipStream_t stream = nullptr, side = nullptr;      // side: the assembly's scalar multiplications, beside the MSMs
         hipEvent_t ev_ab = nullptr, ev_fs = nullptr, ev_b2 = nullptr;
+        hipEvent_t ev_few = nullptr;    // completion of this lane's latest k_solver_few launch (FewSolverChain)
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
@@ -145,7 +155,8 @@ class AlgorithmImpl {
         DevBuf<G1Xyzz> d_sj1[NSETS], d_flat1[NSETS]; DevBuf<G2Xyzz> d_sj2, d_flat2;
         MsmHornerJobs pending1{}, pending2{};
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
-        ~Lane() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (ev_b2) (void)hipEventDestroy(ev_b2); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
+        ~Lane() { if (ev_few) { for (int d = 0; d < 64; d++) { FewSolverChain& c = few_solver_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_few) c.last = nullptr; } (void)hipEventDestroy(ev_few); }
+                  for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (ev_b2) (void)hipEventDestroy(ev_b2); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;
     size_t cap = 0;                     // proofs per lane = the largest chunk
@@ -497,6 +508,7 @@ class AlgorithmImpl {
         ln.cap = B;
         HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side));
         for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming));
         ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
@@ -549,7 +561,7 @@ class AlgorithmImpl {
         n = (nbases + per - 1) / per;
         return n ? n : 1;
     }
-    bool few_solver_wanted(size_t n, size_t B) const { return n <= MSM_FEW_PROOFS && B == 64 && cfg.few_solver; }
+    bool few_solver_wanted(size_t n, size_t B) const { return n <= (size_t)cfg.few_max && B == 64 && cfg.few_solver; }
     struct MsmCtx { hipStream_t stream; uint4* digits; uint8_t* gok; };
     template <class XyzzT, class LR>
     void reduce_slices(hipStream_t st, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, XyzzT* out, LR launch_reduce) {
@@ -571,7 +583,7 @@ class AlgorithmImpl {
         size_t per = 0;
         if (set.nflat) {
             MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ctx.digits, set.nbit, set.group_ok.p, ctx.gok, wires ? 1 : 0};
-            if (n_real <= MSM_FEW_PROOFS && cfg.few_path) {       // a single Prove call: lanes = octets of bases (columns of the padding proofs: the point at infinity)
+            if (n_real <= (size_t)cfg.few_max && cfg.few_path) {       // a single Prove call: lanes = octets of bases (columns of the padding proofs: the point at infinity)
                 const size_t nslices = ((set.nflat + 7) / 8 + 63) / 64;
                 launch_msm_recode_flat_few(ra, n_real, ctx.stream);
                 HIP_CHECK(hipMemsetAsync(pa, 0, nslices * B * sizeof(XyzzT), ctx.stream));
@@ -591,7 +603,7 @@ class AlgorithmImpl {
         if (set.nwide) {
             // a single Prove call (lanes = bases): slices of 512 bases — 8 gathers + 6 butterfly additions per wave, and at most 64 partial
             // sums per column, which one reduction launch folds
-            const bool few = n_real <= MSM_FEW_PROOFS && cfg.few_path;
+            const bool few = n_real <= (size_t)cfg.few_max && cfg.few_path;
             size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, cfg.win_slice, B, per);
             if (few && nslices > (set.nwide + 511) / 512) { per = 512; nslices = (set.nwide + 511) / 512; }
             const size_t Bw = B * (size_t)set.nwin;
@@ -635,7 +647,7 @@ class AlgorithmImpl {
         HIP_CHECK(hipStreamSynchronize(ln.stream));
     }
 
-    void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg) {
+    void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver = true) {
         const size_t B = (n + 63) / 64 * 64;
         ln.n_real = n;
         const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
@@ -664,9 +676,11 @@ class AlgorithmImpl {
             if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[16 * l] = ~0ull;
             d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
         }
-        const bool few_solver = few_solver_wanted(n, B);
+        const bool few_solver = few_solver_wanted(n, B) && allow_few_solver;
+        if (few_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
         SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
-                         ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, (uint32_t)cfg.few_coherent, n_levels, nullptr};
+                         ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, 1u << 21, 0u, (uint32_t)cfg.few_coherent, n_levels, nullptr};
+        if (getenv("GSC_FEW_TEST_ABORT") && getenv("GSC_ENABLE_TEST_HOOKS")) { fa.poll_limit = 256; fa.test_missing = 1; }      // test: the barrier never fills
         auto run_levels = [&](uint32_t from, uint32_t to) {
             for (uint32_t l = from; l < to; l++) {
                 sa.first_level = l; sa.n_long = level_long[l];
@@ -674,8 +688,15 @@ class AlgorithmImpl {
                 else if (few_solver) {                   // a run of generic levels: one launch, device-wide barriers in between
                     uint32_t e = l + 1; while (e < to && !level_kind[e]) e++;
                     fa.from = l; fa.to = e; fa.trace = sa.trace;
-                    HIP_CHECK(hipMemsetAsync(ln.d_fsync.p, 0, 8, ln.stream));
-                    launch_solver_few(fa, has_div, (uint32_t)cfg.few_workgroups, ln.stream);
+                    HIP_CHECK(hipMemsetAsync(ln.d_fsync.p, 0, 4, ln.stream));
+                    {
+                        FewSolverChain& chain = few_solver_chain(cfg.device);
+                        std::lock_guard<std::mutex> lk(chain.m);
+                        if (chain.last && chain.last != ln.ev_few) HIP_CHECK(hipStreamWaitEvent(ln.stream, chain.last, 0));
+                        launch_solver_few(fa, has_div, cfg.few_workgroups ? (uint32_t)cfg.few_workgroups : (n <= 2 ? 128u : 256u), ln.stream);      // measured: 128 workgroups best for 1-2 statements, 256 (one per CU) beyond
+                        HIP_CHECK(hipEventRecord(ln.ev_few, ln.stream));
+                        chain.last = ln.ev_few;
+                    }
                     l = e - 1;
                 } else launch_solver_level(sa, level_width[l], ln.stream);
             }
@@ -715,7 +736,7 @@ class AlgorithmImpl {
         }
         // A latency-path call leaves the chip mostly idle, so its A and B1 sums and the two scalar multiplications that need them (s * Ar,
         // r * Bs1: 254 serial doublings, 2 ms) start on the side stream right after the witness, beside the quotient and the other MSMs.
-        const bool early_ab = ln.n_real <= MSM_FEW_PROOFS && cfg.few_path && B == 64 && !mA.nwide && !mB1.nwide;
+        const bool early_ab = ln.n_real <= (size_t)cfg.few_max && cfg.few_path && B == 64 && !mA.nwide && !mB1.nwide;
         if (early_ab) {
             HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
             HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
@@ -747,7 +768,7 @@ class AlgorithmImpl {
         }
         HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
         run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
-        run_msm_g1(ln, ln.n_real <= MSM_FEW_PROOFS && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, true);
+        run_msm_g1(ln, ln.n_real <= (size_t)cfg.few_max && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, true);
         if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
         flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
         if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
@@ -763,9 +784,16 @@ class AlgorithmImpl {
         HIP_CHECK(hipMemcpyAsync(h_flags.data(), ln.d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, ln.stream));
         HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
         if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
+        uint32_t h_fsync[2] = {0, 0};
+        if (few_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
         const auto tc1 = std::chrono::steady_clock::now();
         HIP_CHECK(hipStreamSynchronize(ln.stream));
         const auto tc2 = std::chrono::steady_clock::now();
+        if (h_fsync[1]) {      // the resident solver gave up (its workgroups never became resident together: another process's kernel on this device)
+            static std::atomic<bool> warned{false};
+            if (!warned.exchange(true)) fprintf(stderr, "libprove: the resident witness kernel could not hold the device (shared with another process?); solving level by level\n");
+            return prove_chunk(ln, reqs, n, results, dbg, false);
+        }
         for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
         (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
         for (size_t i = 0; i < n; i++)

@@ -252,11 +252,10 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
 // statements' own columns are written (one lane's store per value): the other columns of the 64-wide batch keep what they held —
 // zero from the allocation or an earlier call's witness, field elements either way, which is all the transforms and MSMs ask.
 // The grid is far smaller than the chip (<= 1 workgroup per CU), so every workgroup is resident; a barrier that is not reached
-// within ~2 s of polling (it cannot be, short of a fault elsewhere) raises the abort bit, every workgroup leaves, and the
-// statements are reported as failed — no wave waits forever.
+// within ~2 s of polling (another process's resident kernel holding CUs; the engine chains its own launches) raises the abort
+// bit, every workgroup leaves — no wave waits forever — and the host solves the call again with one launch per level.
 constexpr uint32_t FEW_WAVES = 8;
 constexpr uint32_t FEW_ABORT = 0x80000000u;
-constexpr uint32_t FEW_POLL_LIMIT = 1u << 21;
 
 __device__ __forceinline__ fe readlane_fe(const fe& v, uint32_t src) {
     fe r;
@@ -285,7 +284,7 @@ __device__ __forceinline__ void store_wire(fe* p, const fe& v, bool dev) {
     for (int k = 0; k < 4; k++) __hip_atomic_store(q + k, (unsigned long long)v.l[2 * k] | ((unsigned long long)v.l[2 * k + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // false: the barrier was abandoned (abort bit), the caller returns
-__device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target, unsigned long long* stamps, bool dev) {
+__device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target, unsigned long long* stamps, bool dev, uint32_t poll_limit) {
     __shared__ uint32_t s_ok;
     __syncthreads();                         // every wave's stores have left the CU (write-through L1)
     if (threadIdx.x == 0) {
@@ -295,7 +294,7 @@ __device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t polls = 0, seen;
         while ((seen = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
-            if (++polls > FEW_POLL_LIMIT) { seen = __hip_atomic_fetch_or(sync, FEW_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | FEW_ABORT; break; }
+            if (++polls > poll_limit) { seen = __hip_atomic_fetch_or(sync, FEW_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | FEW_ABORT; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         if (stamps) stamps[4] = wall_clock64();
@@ -533,8 +532,9 @@ __global__ __launch_bounds__(64 * FEW_WAVES) void k_solver_few(SolverFewArgs a) 
         if (lev + 1 == a.to) { if (stamps && threadIdx.x == 0) { a.trace[16 * a.nlev_trace + 2] = wall_clock64(); a.trace[16 * a.nlev_trace + 3] = clock64(); } break; }
         l0 = l1; l1 = a.level_start[lev + 2];
         f = few_fetch(a, op_of(l0, gw < (l1 - l0) * a.n_real ? gw : 0u), lane);            // static data of the next level's item: in flight across the barrier
-        if (!few_grid_barrier(a.sync, ++epoch * gridDim.x, stamps, a.coherent != 0)) {
-            if (threadIdx.x < a.n_real && blockIdx.x == 0) atomicMin(a.status + threadIdx.x, 0u);      // reported as unsatisfied
+        if (!few_grid_barrier(a.sync, ++epoch * (gridDim.x + a.test_missing), stamps, a.coherent != 0, a.poll_limit)) {
+            if (threadIdx.x < a.n_real && blockIdx.x == 0) atomicMin(a.status + threadIdx.x, 0u);      // unsatisfied, unless the host solves the call again:
+            if (threadIdx.x == 0) atomicOr(a.sync + 1, 1u);                                              // sync[1] tells it that the launch gave up
             return;
         }
     }

@@ -66,6 +66,7 @@ struct SolverFewArgs {
     fe* W; fe* A; fe* B; fe* C; size_t batch; uint32_t n_real;
     uint32_t* status; const fe* mask; const fe* commit;
     uint32_t* sync;
+    uint32_t poll_limit, test_missing;              // barrier polls before giving up; test hook: arrivals that never come (exercises the give-up path)
     uint32_t coherent;                              // 1: wire values move with device-scope accesses, the barrier does no cache maintenance (k_solver.hip load_wire)
     uint32_t nlev_trace;                            // diagnostics: slot of the whole-launch stamps in trace (the program's level count)
     unsigned long long* trace;                      // diagnostics (GSC_SOLVER_TRACE): per level stamps of workgroup 0 (100 MHz clock: level in, first item done, workgroup done, released, all arrived, acquired), or nullptr
@@ -141,7 +142,7 @@ void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s);
 void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s);
 // The same partial sums for the first `nproofs` proofs only (columns nproofs .. batch-1 of `partial` are not written): lanes are bases
 // instead of proofs — the latency path of a single Prove call.  Worth it below MSM_FEW_PROOFS proofs.
-constexpr size_t MSM_FEW_PROOFS = 8;
+constexpr size_t MSM_FEW_PROOFS = 32;     // layout bound of the latency kernels; the engine's threshold is EngineConfig::few_max
 void launch_msm_win_few_g1(const MsmWinArgs& a, size_t nproofs, hipStream_t s);
 void launch_msm_win_few_g2(const MsmWinArgs& a, size_t nproofs, hipStream_t s);
 // out[p] = sum_j 2^(c j) S[j * batch + p] (+ addend[p] when addend != nullptr), for up to MSM_HORNER_JOBS independent sets in one launch

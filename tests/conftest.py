@@ -6,6 +6,11 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["GSC_ENABLE_TEST_HOOKS"] = "1"      # read once by libprove.so when it is loaded (include/libprove.h, TEST HOOKS)
+# The GPU session keeps ChaCha20, AES-128 and AES-256 loaded at once and starts child processes with their own tables beside them:
+# smaller quotient tables than the defaults (c = 14 / 12 instead of 15 / 13; latency layout 8.6 GB + 2 x 4.3 GB) leave room on the
+# 288 GB device.  Results do not depend on the table sizes (tests/test_gpu_parity.py checks that).
+os.environ.setdefault("GSC_Z_TABLE_GB", "24")
+os.environ.setdefault("GSC_FEW_Z_GB", "9")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -247,10 +247,27 @@ def test_latency_path_options_do_not_change_the_proofs(aes_keys, algo, counts):
     # GSC_FEW_SOLVER=0), whatever the grid, the barrier's memory mode or the quotient layout.
     from conftest import ROOT
     pk_path = os.path.join(ROOT, "build", "keys", "pk.aes128") if algo else None
+    small = {"GSC_MAX_BATCH": "64", "GSC_LANES": "1"}
     for n in counts:
-        base = _digest({"TEST_STATEMENTS": n, "GSC_FEW_PATH": "0", "GSC_FEW_SOLVER": "0"}, algo, pk_path)
-        for extra in ({"GSC_FEW_Z_GB": "12"}, {"GSC_FEW_Z_GB": "0"}, {"GSC_FEW_Z_GB": "12", "GSC_FEW_COHERENT": "0", "GSC_FEW_WGS": "17"}, {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": "3"}):
-            assert _digest(dict(extra, TEST_STATEMENTS=n), algo, pk_path) == base, (n, extra)
+        base = _digest(dict(small, TEST_STATEMENTS=n, GSC_FEW_PATH="0", GSC_FEW_SOLVER="0"), algo, pk_path)
+        # quotient layout budgets: ChaCha20 8-bit rows (8.6 GB) and 6-bit ones (2.9 GB); AES 4-bit rows (4.3 GB: the session's own algorithms hold most of the device)
+        z, z2 = ("12", "3") if algo == 0 else ("5", "5")
+        for extra in ({"GSC_FEW_Z_GB": z}, {"GSC_FEW_Z_GB": "0"}, {"GSC_FEW_Z_GB": z, "GSC_FEW_COHERENT": "0", "GSC_FEW_WGS": "17"}, {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": z2}):
+            assert _digest(dict(small, TEST_STATEMENTS=n, **extra), algo, pk_path) == base, (n, extra)
+
+
+def test_resident_solver_gives_up_cleanly_and_the_call_is_solved_again():
+    # The resident witness kernel polls its device-wide barriers a bounded number of times.  GSC_FEW_TEST_ABORT (a test hook) makes a
+    # barrier unreachable: every workgroup must leave, and the engine must solve the call again with one launch per level — same bytes,
+    # one line on stderr.
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_FEW_Z_GB="0", TEST_STATEMENTS="3")
+    want = _digest({"TEST_STATEMENTS": "3"})
+    out = subprocess.run([sys.executable, "-c", _OPTIONS_SCRIPT, ROOT, "0"], env=dict(env, GSC_FEW_TEST_ABORT="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0] == want
+    assert "solving level by level" in out.stderr
 
 
 def test_bench_size_batch_every_proof_verifies(gsc_chacha):
