@@ -136,8 +136,8 @@ class AlgorithmImpl {
     // NOT beat one lane with the same number of proofs in flight (the MSM kernels already fill the chip and two of them thrash
     // each other's table gathers), so the default is one lane; the option stays for hosts that prefer lower per-call latency.
     struct Lane {
-        hipStream_t stream = nullptr, side = nullptr;      // side: the assembly's scalar multiplications, beside the MSMs
-        hipEvent_t ev_ab = nullptr, ev_fs = nullptr, ev_b2 = nullptr;
+        hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;      // side: the assembly's scalar multiplications, beside the MSMs; side2: the B2 sum of a latency-path call
+        hipEvent_t ev_ab = nullptr, ev_fs = nullptr, ev_b2 = nullptr, ev_s2 = nullptr;
         hipEvent_t ev_few = nullptr;    // completion of this lane's latest k_solver_few launch (FewSolverChain)
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
@@ -147,6 +147,7 @@ class AlgorithmImpl {
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
+        DevBuf<uint4> d_digits_s2; DevBuf<uint8_t> d_gok_s2;                                        // side2's digits (its partial sums are the G2 buffers, which nothing else uses)
         DevBuf<uint4> d_digits_s; DevBuf<uint8_t> d_gok_s; DevBuf<G1Xyzz> d_part1c, d_part1d;      // the side stream's MSM scratch (A and B1 of a latency-path call)
         DevBuf<uint4> d_digits;                                                   // signed digits [window][octet][proof]
         // per-window sums [window][proof] and flat-part sums [proof], one pair per set: the Horner passes of several sets are deferred
@@ -156,7 +157,7 @@ class AlgorithmImpl {
         MsmHornerJobs pending1{}, pending2{};
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
         ~Lane() { if (ev_few) { for (int d = 0; d < 64; d++) { FewSolverChain& c = few_solver_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_few) c.last = nullptr; } (void)hipEventDestroy(ev_few); }
-                  for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (ev_b2) (void)hipEventDestroy(ev_b2); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
+                  for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (ev_b2) (void)hipEventDestroy(ev_b2); if (ev_s2) (void)hipEventDestroy(ev_s2); if (side2) (void)hipStreamDestroy(side2); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;
     size_t cap = 0;                     // proofs per lane = the largest chunk
@@ -508,10 +509,10 @@ class AlgorithmImpl {
 
     void alloc_lane(Lane& ln, size_t B) {
         ln.cap = B;
-        HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side));
+        HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side)); HIP_CHECK(hipStreamCreate(&ln.side2));
         for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
         ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
         // calls with a handful of statements (k_solver_few) write their own columns only: the others must always hold field elements
@@ -544,6 +545,7 @@ class AlgorithmImpl {
                 if (m->nbit / 8 * MSM_FEW_PROOFS > gks) gks = m->nbit / 8 * MSM_FEW_PROOFS;
                 if (nsl * 64 > ps) ps = nsl * 64;
             }
+            ln.d_digits_s2.alloc(((mB2.nflat + 7) / 8) * 64 + 1); ln.d_gok_s2.alloc(mB2.nbit / 8 * MSM_FEW_PROOFS + 1);
             ln.d_digits_s.alloc(dgs); ln.d_gok_s.alloc(gks); ln.d_part1c.alloc(ps); ln.d_part1d.alloc((ps / 64 + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * 64 + 64);
         }
         for (int k = 0; k < Lane::NSETS; k++) { ln.d_sj1[k].alloc(sj1[k] ? sj1[k] : 1); ln.d_flat1[k].alloc(g1sets[k]->nflat && g1sets[k]->nwide ? B : 1); }
@@ -637,8 +639,9 @@ class AlgorithmImpl {
         }
         run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
     }
-    void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum) {
-        run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2);
+    void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum, bool side = false) {
+        if (side && (set.nwide || B != 64)) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
+        run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2);
     }
     void flush_horner_g1(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g1(ln.pending1, B, s); ln.pending1.n = 0; }
     void flush_horner_g2(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g2(ln.pending2, B, s); ln.pending2.n = 0; }
@@ -746,6 +749,12 @@ class AlgorithmImpl {
             run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p, false, true);
             launch_fin_scalarmul_few(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.n_real, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
         }
+        const bool early_b2 = early_ab && !mB2.nwide;         // the G2 sum too (it only reads the witness): a third stream
+        if (early_b2) {
+            HIP_CHECK(hipStreamWaitEvent(ln.side2, ln.ev_ab, 0));
+            run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p, true);
+            HIP_CHECK(hipEventRecord(ln.ev_s2, ln.side2));
+        }
         // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
         NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
         HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
@@ -762,7 +771,7 @@ class AlgorithmImpl {
             HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
             launch_fin_scalarmul(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
         }
-        run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p);
+        if (!early_b2) run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p);
         if (ln.pending2.n) {                                                         // the G2 Horner chain (3x a G1 one) also goes beside the MSMs
             HIP_CHECK(hipEventRecord(ln.ev_b2, ln.stream));
             HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_b2, 0));
@@ -778,6 +787,7 @@ class AlgorithmImpl {
         HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
         // 4. assembly
         HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_fs, 0));
+        if (early_b2) HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_s2, 0));
         launch_fin_combine(ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, ln.d_tmp.p, B, ln.d_out.p, ln.d_flags.p, ln.stream);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
