@@ -60,6 +60,9 @@ struct MsmSet {                     // one fixed-base MSM of the proving key (ke
     // flat part: [bit groups of eight][narrow wires, own row lengths][window octets of a few wide wires (cv-bit digits)]
     DevBuf<AffT> ftable; DevBuf<uint64_t> rowoff; DevBuf<uint32_t> rowlen; DevBuf<uint32_t> frows; DevBuf<int32_t> octwin;
     size_t nflat = 0, nbit = 0, nexpanded = 0; int cv = 0; DevBuf<AffT> sub; DevBuf<uint8_t> group_ok;
+    // latency path: the windowed part once more as a flat set of (base, window) rows of 8-bit digits (no Horner pass behind it)
+    std::unique_ptr<MsmSet<AffT>> few_wide;
+    bool latency_flat() const { return !nwide || few_wide; }       // calls with a handful of statements need no windowed kernel for this set
 };
 
 }  // namespace
@@ -87,6 +90,7 @@ EngineConfig config_from_env() {
     c.few_workgroups = env_int("GSC_FEW_WGS", 0);
     c.few_coherent = env_int("GSC_FEW_COHERENT", 1);
     c.few_z_gb = env_int("GSC_FEW_Z_GB", 12);
+    c.few_wide = env_int("GSC_FEW_WIDE", 1);
     if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");
     c.win_slice = (size_t)env_int("GSC_WIN_SLICE", 256);
     if (c.win_slice < 8 || c.win_slice > 4096) throw std::runtime_error("GSC_WIN_SLICE must be in [8, 4096]");
@@ -163,8 +167,8 @@ class AlgorithmImpl {
     size_t cap = 0;                     // proofs per lane = the largest chunk
 
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf) : cipher(c), cfg(cf) {
-        // measured crossover with the batch kernels (one 64-column batch: 12.3 ms ChaCha20, 44 ms AES): 32 statements for ChaCha20 (11.3 ms), ~12 for AES (1.7 ms each on top of 22)
-        if (!cfg.few_max) cfg.few_max = cipher == CHACHA20 ? 32 : 8;
+        // measured crossover with the batch kernels (one 64-column batch: 12.9 ms ChaCha20, 43 ms AES): 32 statements for ChaCha20 (11.4 ms), ~15 for AES (15 ms + 1.9 ms each)
+        if (!cfg.few_max) cfg.few_max = cipher == CHACHA20 ? 32 : 12;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the GPU prover has no CPU fallback");
         HIP_CHECK(hipSetDevice(cfg.device));
@@ -412,6 +416,12 @@ class AlgorithmImpl {
             build_rows<AffT, XyzzT>(wb.p, set.nwide, off, len, set.wtable.p);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipStreamSynchronize(stream));
+            if (!uniform && cfg.few_path && cfg.few_wide) {      // (the quotient bases have their own budgeted layout: init_key)
+                std::vector<uint8_t> raw_w(set.nwide * point_bytes); std::vector<uint32_t> rows_w(set.nwide);
+                for (size_t i = 0; i < set.nwide; i++) { memcpy(raw_w.data() + i * point_bytes, raw.data() + (size_t)wide[i] * point_bytes, point_bytes); rows_w[i] = rows[wide[i]]; }
+                set.few_wide.reset(new MsmSet<AffT>());
+                build_set<AffT, XyzzT>(*set.few_wide, raw_w, point_bytes, rows_w, c, what, decomp, true, 8);
+            }
         }
     }
     // group tables are built in chunks so that the projective scratch stays below ~2 GiB
@@ -528,6 +538,11 @@ class AlgorithmImpl {
             };
             size_t per = 0;
             if (m.nflat) { part(m.nflat, msm_slices(m.nflat, 1, 256, b, per), b); if (m.nflat / 8 * b > dg) dg = m.nflat / 8 * b; if (m.nbit / 8 * (b / 64) > gk) gk = m.nbit / 8 * (b / 64); if (m.nbit / 8 * MSM_FEW_PROOFS > gk) gk = m.nbit / 8 * MSM_FEW_PROOFS; }
+            if (b == 64 && m.few_wide) {      // latency layout of the wide wires: digits of its octets, partial sums of both parts side by side
+                const size_t o2 = (m.few_wide->nflat + 7) / 8;
+                if (o2 * 64 > dg) dg = o2 * 64;
+                part(0, ((m.nflat + 7) / 8 + 63) / 64 + (o2 + 63) / 64, 64);
+            }
             if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, cfg.win_slice, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
         };
         MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew};
@@ -540,12 +555,14 @@ class AlgorithmImpl {
         {
             size_t dgs = 1, gks = 1, ps = 1;
             for (const MsmSet<G1Aff>* m : {&mA, &mB1}) {
-                const size_t noct = (m->nflat + 7) / 8, nsl = (noct + 63) / 64;
+                const size_t noct = (m->nflat + 7) / 8, nsl = (noct + 63) / 64, noctw = m->few_wide ? (m->few_wide->nflat + 7) / 8 : 0, nslw = (noctw + 63) / 64;
                 if (noct * 64 > dgs) dgs = noct * 64;
+                if (noctw * 64 > dgs) dgs = noctw * 64;
                 if (m->nbit / 8 * MSM_FEW_PROOFS > gks) gks = m->nbit / 8 * MSM_FEW_PROOFS;
-                if (nsl * 64 > ps) ps = nsl * 64;
+                if ((nsl + nslw) * 64 > ps) ps = (nsl + nslw) * 64;
             }
-            ln.d_digits_s2.alloc(((mB2.nflat + 7) / 8) * 64 + 1); ln.d_gok_s2.alloc(mB2.nbit / 8 * MSM_FEW_PROOFS + 1);
+            { const size_t o1 = (mB2.nflat + 7) / 8, o2 = mB2.few_wide ? (mB2.few_wide->nflat + 7) / 8 : 0; ln.d_digits_s2.alloc((o1 > o2 ? o1 : o2) * 64 + 1); }
+            ln.d_gok_s2.alloc(mB2.nbit / 8 * MSM_FEW_PROOFS + 1);
             ln.d_digits_s.alloc(dgs); ln.d_gok_s.alloc(gks); ln.d_part1c.alloc(ps); ln.d_part1d.alloc((ps / 64 + MSM_REDUCE_FANIN - 1) / MSM_REDUCE_FANIN * 64 + 64);
         }
         for (int k = 0; k < Lane::NSETS; k++) { ln.d_sj1[k].alloc(sj1[k] ? sj1[k] : 1); ln.d_flat1[k].alloc(g1sets[k]->nflat && g1sets[k]->nwide ? B : 1); }
@@ -578,24 +595,57 @@ class AlgorithmImpl {
             XyzzT* t = src; src = dst; alt = t; ns = groups;
         }
     }
+    // the same for the first `npr` columns of every row of `stride` (latency path: nobody reads the padding proofs' columns)
+    template <class XyzzT, class LRF>
+    void reduce_slices_few(hipStream_t st, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, size_t stride, size_t npr, XyzzT* out, LRF launch_reduce_few) {
+        XyzzT* src = pa; XyzzT* alt = pb; size_t ns = nslices;
+        for (;;) {
+            const size_t groups = (ns + 63) / 64;
+            XyzzT* dst = groups == 1 ? out : alt;
+            launch_reduce_few(src, ns, cols, stride, npr, dst, st);
+            if (groups == 1) break;
+            XyzzT* t = src; src = dst; alt = t; ns = groups;
+        }
+    }
     // scalars: the wire matrix W (Montgomery; wire sets) or h (canonical; Z)
     // The Horner pass of the windowed part is NOT launched here: it is queued in `pending` and flushed together with those of other
     // sets (flush_horner_*), because each is a serial chain of 254 doublings whose duration does not depend on the batch.
-    template <class AffT, class XyzzT, class LF, class LFF, class LW, class LWF, class LR>
+    template <class AffT, class XyzzT, class LF, class LFF, class LW, class LWF, class LR, class LRF>
     void run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
-                 MsmHornerJobs& pending, LF launch_flat, LFF launch_flat_few, LW launch_win, LWF launch_win_few, LR launch_reduce) {
+                 MsmHornerJobs& pending, LF launch_flat, LFF launch_flat_few, LW launch_win, LWF launch_win_few, LR launch_reduce, LRF launch_reduce_few) {
         size_t per = 0;
+        const bool fewm = n_real <= (size_t)cfg.few_max && cfg.few_path;
+        if (fewm && set.latency_flat()) {
+            // a call with a handful of statements, every part of the set as flat rows: lanes = octets of bases, the partial sums of both
+            // parts side by side, one reduction, no Horner pass
+            size_t ns = 0;
+            auto part = [&](const MsmSet<AffT>& m, bool stamp) {
+                if (!m.nflat) return;
+                const size_t nslices = ((m.nflat + 7) / 8 + 63) / 64;
+                MsmFlatRecodeArgs ra{scalars, m.frows.p, m.octwin.p, m.nflat, B, m.cv, ctx.digits, m.nbit, m.group_ok.p, ctx.gok, wires ? 1 : 0};
+                launch_msm_recode_flat_few(ra, n_real, ctx.stream);
+                MsmFlatArgs a{m.ftable.p, m.rowoff.p, m.rowlen.p, m.nflat, ctx.digits, B, nslices, 512, pa + ns * B, m.nbit, m.sub.p, ctx.gok, scalars, m.frows.p};
+                if (stamp) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
+                launch_flat_few(a, n_real, ctx.stream);
+                if (stamp) HIP_CHECK(hipEventRecord(ln.ev[6], ctx.stream));
+                ns += nslices;
+            };
+            part(set, timed);
+            if (set.few_wide) part(*set.few_wide, false);
+            if (ns) reduce_slices_few(ctx.stream, pa, pb, ns, B, B, n_real, sum, launch_reduce_few);
+            else HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ctx.stream));
+            return;
+        }
         if (set.nflat) {
             MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ctx.digits, set.nbit, set.group_ok.p, ctx.gok, wires ? 1 : 0};
-            if (n_real <= (size_t)cfg.few_max && cfg.few_path) {       // a single Prove call: lanes = octets of bases (columns of the padding proofs: the point at infinity)
+            if (fewm) {       // (a set whose windowed part has no latency layout: GSC_FEW_WIDE=0)
                 const size_t nslices = ((set.nflat + 7) / 8 + 63) / 64;
                 launch_msm_recode_flat_few(ra, n_real, ctx.stream);
-                HIP_CHECK(hipMemsetAsync(pa, 0, nslices * B * sizeof(XyzzT), ctx.stream));
                 MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ctx.digits, B, nslices, 512, pa, set.nbit, set.sub.p, ctx.gok, scalars, set.frows.p};
                 if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
                 launch_flat_few(a, n_real, ctx.stream);
                 if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ctx.stream));
-                reduce_slices(ctx.stream, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
+                reduce_slices_few(ctx.stream, pa, pb, nslices, B, B, n_real, set.nwide ? flat : sum, launch_reduce_few);
             } else {
                 const size_t nslices = msm_slices(set.nflat, 1, 256, B, per);
                 launch_msm_recode_flat(ra, ctx.stream);
@@ -607,7 +657,7 @@ class AlgorithmImpl {
         if (set.nwide) {
             // a single Prove call (lanes = bases): slices of 512 bases — 8 gathers + 6 butterfly additions per wave, and at most 64 partial
             // sums per column, which one reduction launch folds
-            const bool few = n_real <= (size_t)cfg.few_max && cfg.few_path;
+            const bool few = fewm;
             size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, cfg.win_slice, B, per);
             if (few && nslices > (set.nwide + 511) / 512) { per = 512; nslices = (set.nwide + 511) / 512; }
             const size_t Bw = B * (size_t)set.nwin;
@@ -616,12 +666,11 @@ class AlgorithmImpl {
             MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa, cfg.msm_placement, 0};
             if (const char* e = getenv("GSC_MSM_EXP")) { if (getenv("GSC_ENABLE_TEST_HOOKS") && (atoi(e) & 1)) a.exp_same_entry = 1; if (atoi(e) & 2) a.placement = 1; if (atoi(e) & 4) a.placement = 0; }
             if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
-            if (few) {      // columns of the padding proofs: the point at infinity
-                HIP_CHECK(hipMemsetAsync(pa, 0, nslices * Bw * sizeof(XyzzT), ctx.stream));
-                launch_win_few(a, n_real, ctx.stream);
-            } else launch_win(a, ctx.stream);
+            if (few) launch_win_few(a, n_real, ctx.stream);
+            else launch_win(a, ctx.stream);
             if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ctx.stream));
-            reduce_slices(ctx.stream, pa, pb, nslices, Bw, sj, launch_reduce);      // slices -> one sum per (window, proof)
+            if (few) reduce_slices_few(ctx.stream, pa, pb, nslices, Bw, B, n_real, sj, launch_reduce_few);
+            else reduce_slices(ctx.stream, pa, pb, nslices, Bw, sj, launch_reduce);      // slices -> one sum per (window, proof)
             if (pending.n >= MSM_HORNER_JOBS) throw std::runtime_error("internal: too many pending Horner passes");
             pending.job[pending.n++] = MsmHornerJob{sj, set.nflat ? flat : (XyzzT*)nullptr, sum, set.nwin, set.c};
         }
@@ -632,16 +681,16 @@ class AlgorithmImpl {
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false, bool side = false) {
         const int k = set_index(set);
         if (side) {
-            if (set.nwide || B != 64) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
+            if (!set.latency_flat() || B != 64) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
             run_msm(ln, MsmCtx{ln.side, ln.d_digits_s.p, ln.d_gok_s.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1c.p, ln.d_part1d.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, false, ln.pending1,
-                    launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
+                    launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
             return;
         }
-        run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1);
+        run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
     }
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum, bool side = false) {
-        if (side && (set.nwide || B != 64)) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
-        run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2);
+        if (side && (!set.latency_flat() || B != 64)) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
+        run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_reduce_few_g2);
     }
     void flush_horner_g1(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g1(ln.pending1, B, s); ln.pending1.n = 0; }
     void flush_horner_g2(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g2(ln.pending2, B, s); ln.pending2.n = 0; }
@@ -741,7 +790,7 @@ class AlgorithmImpl {
         }
         // A latency-path call leaves the chip mostly idle, so its A and B1 sums and the two scalar multiplications that need them (s * Ar,
         // r * Bs1: 254 serial doublings, 2 ms) start on the side stream right after the witness, beside the quotient and the other MSMs.
-        const bool early_ab = ln.n_real <= (size_t)cfg.few_max && cfg.few_path && B == 64 && !mA.nwide && !mB1.nwide;
+        const bool early_ab = ln.n_real <= (size_t)cfg.few_max && cfg.few_path && B == 64 && mA.latency_flat() && mB1.latency_flat();
         if (early_ab) {
             HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
             HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
@@ -749,7 +798,7 @@ class AlgorithmImpl {
             run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p, false, true);
             launch_fin_scalarmul_few(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.n_real, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
         }
-        const bool early_b2 = early_ab && !mB2.nwide;         // the G2 sum too (it only reads the witness): a third stream
+        const bool early_b2 = early_ab && mB2.latency_flat();         // the G2 sum too (it only reads the witness): a third stream
         if (early_b2) {
             HIP_CHECK(hipStreamWaitEvent(ln.side2, ln.ev_ab, 0));
             run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p, true);

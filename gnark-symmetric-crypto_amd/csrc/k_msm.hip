@@ -54,6 +54,23 @@ __global__ __launch_bounds__(64) void k_msm_reduce(const fe* partial, size_t nsl
     if (threadIdx.x == 0) C::store_xyzz(out + (grp * batch + p) * (4 * F::WORDS), v);
 }
 
+// the butterfly for calls with a handful of statements: only the columns of the first `npr` proofs of every row of `stride` columns
+// (a row = a window; one row for a flat set) — the other columns of the 64-wide batch hold nothing anybody reads
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_reduce_few(const fe* partial, size_t nslices, size_t cols, fe* out, uint32_t npr, uint32_t stride) {
+    using C = Curve9<F>;
+    const size_t p = (size_t)(blockIdx.x / npr) * stride + blockIdx.x % npr, grp = blockIdx.y;
+    const size_t slice = grp * 64 + threadIdx.x;
+    Xyzz9<F> v = slice < nslices ? C::load_xyzz(partial + (slice * cols + p) * (4 * F::WORDS)) : C::infinity();
+    for (int m = 32; m >= 1; m >>= 1) {
+        Xyzz9<F> o;
+        o.x = shfl_xor_e(v.x, m); o.y = shfl_xor_e(v.y, m); o.zz = shfl_xor_e(v.zz, m); o.zzz = shfl_xor_e(v.zzz, m);
+        o.inf = __shfl_xor((int)v.inf, m) != 0;
+        v = C::add(v, o);
+    }
+    if (threadIdx.x == 0) C::store_xyzz(out + (grp * cols + p) * (4 * F::WORDS), v);
+}
+
 // the same sum with lanes = proofs: every lane adds up to MSM_REDUCE_FANIN slice partials of ITS proof one after the other.  No lane
 // idles (the butterfly above keeps 64 lanes busy for 63 useful additions out of 384), loads are coalesced; used whenever the
 // batch is large enough to fill the chip this way (launch_msm_reduce picks).
@@ -273,6 +290,16 @@ static size_t launch_msm_reduce(const fe* partial, size_t nslices, size_t batch,
     const size_t groups = msm_reduce_groups(nslices, batch);
     if (msm_reduce_by_proof(nslices, batch)) hipLaunchKernelGGL(k_msm_reduce_seq<F>, dim3((unsigned)(batch / 64), (unsigned)groups), dim3(64), 0, s, partial, nslices, batch, out);
     else hipLaunchKernelGGL(k_msm_reduce<F>, dim3((unsigned)batch, (unsigned)groups), dim3(64), 0, s, partial, nslices, batch, out);
+    return groups;
+}
+size_t launch_msm_reduce_few_g1(const G1Xyzz* partial, size_t nslices, size_t cols, size_t stride, size_t npr, G1Xyzz* out, hipStream_t s) {
+    const size_t groups = (nslices + 63) / 64;
+    hipLaunchKernelGGL(k_msm_reduce_few<Fp29f>, dim3((unsigned)(cols / stride * npr), (unsigned)groups), dim3(64), 0, s, reinterpret_cast<const fe*>(partial), nslices, cols, reinterpret_cast<fe*>(out), (uint32_t)npr, (uint32_t)stride);
+    return groups;
+}
+size_t launch_msm_reduce_few_g2(const G2Xyzz* partial, size_t nslices, size_t cols, size_t stride, size_t npr, G2Xyzz* out, hipStream_t s) {
+    const size_t groups = (nslices + 63) / 64;
+    hipLaunchKernelGGL(k_msm_reduce_few<Fp2x>, dim3((unsigned)(cols / stride * npr), (unsigned)groups), dim3(64), 0, s, reinterpret_cast<const fe*>(partial), nslices, cols, reinterpret_cast<fe*>(out), (uint32_t)npr, (uint32_t)stride);
     return groups;
 }
 size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s) {

@@ -200,6 +200,10 @@ inline bool msm_reduce_by_proof(size_t nslices, size_t batch) { return (batch / 
 inline size_t msm_reduce_groups(size_t nslices, size_t batch) { const size_t f = msm_reduce_by_proof(nslices, batch) ? MSM_REDUCE_FANIN : 64; return (nslices + f - 1) / f; }
 size_t launch_msm_reduce_g1(const G1Xyzz* partial, size_t nslices, size_t batch, G1Xyzz* out, hipStream_t s);
 size_t launch_msm_reduce_g2(const G2Xyzz* partial, size_t nslices, size_t batch, G2Xyzz* out, hipStream_t s);
+// calls with a handful of statements: `cols` columns in rows of `stride` (= the batch), only the first npr columns of every row are
+// summed (lanes = slices, 64 per wave); returns ceil(nslices / 64); `out` as above
+size_t launch_msm_reduce_few_g1(const G1Xyzz* partial, size_t nslices, size_t cols, size_t stride, size_t npr, G1Xyzz* out, hipStream_t s);
+size_t launch_msm_reduce_few_g2(const G2Xyzz* partial, size_t nslices, size_t cols, size_t stride, size_t npr, G2Xyzz* out, hipStream_t s);
 
 // Groth16 Setup: out[i] = scalars[i] * G for n independent canonical scalars (8 little-endian words each), from the window rows
 // table[j * D + d - 1] = d * 2^(c j) * G, D = 2^(c-1), nwin = msm_windows(c).  out: affine coordinates as canonical integers

@@ -10,6 +10,7 @@ os.environ["GSC_ENABLE_TEST_HOOKS"] = "1"      # read once by libprove.so when i
 # smaller quotient tables than the defaults (c = 14 / 12 instead of 15 / 13; latency layout 8.6 GB + 2 x 4.3 GB) leave room on the
 # 288 GB device.  Results do not depend on the table sizes (tests/test_gpu_parity.py checks that).
 os.environ.setdefault("GSC_Z_TABLE_GB", "24")
+os.environ.setdefault("GSC_W_TABLE_GB", "8")
 os.environ.setdefault("GSC_FEW_Z_GB", "9")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -209,7 +209,7 @@ def _digest(env_extra, algo=0, pk_path=None):
     import subprocess, sys
     from conftest import ROOT
     # small tables: these child processes share the device with the algorithms the test session already holds (~170 GB)
-    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_FEW_Z_GB="0")
+    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_FEW_Z_GB="0", GSC_FEW_WIDE="0")
     env.update(env_extra)
     args = [sys.executable, "-c", _OPTIONS_SCRIPT, ROOT, str(algo)] + ([pk_path] if pk_path else [])
     out = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900)
@@ -244,7 +244,7 @@ def test_latency_path_options_do_not_change_the_proofs(aes_keys, algo, counts):
     # Calls with at most 8 statements take kernels of their own (resident lanes-are-terms solver with device-wide barriers, flat and
     # windowed MSMs with lanes = bases, the quotient bases as (base, window) rows without a Horner pass, A / B1 sums early on the side
     # stream).  With (r, s, mask) fixed, a handful of statements must give the same bytes as the batch kernels (GSC_FEW_PATH=0
-    # GSC_FEW_SOLVER=0), whatever the grid, the barrier's memory mode or the quotient layout.
+    # GSC_FEW_SOLVER=0), whatever the grid, the barrier's memory mode, the quotient layout and the latency rows of the wide wires (GSC_FEW_WIDE).
     from conftest import ROOT
     pk_path = os.path.join(ROOT, "build", "keys", "pk.aes128") if algo else None
     small = {"GSC_MAX_BATCH": "64", "GSC_LANES": "1"}
@@ -252,7 +252,8 @@ def test_latency_path_options_do_not_change_the_proofs(aes_keys, algo, counts):
         base = _digest(dict(small, TEST_STATEMENTS=n, GSC_FEW_PATH="0", GSC_FEW_SOLVER="0"), algo, pk_path)
         # quotient layout budgets: ChaCha20 8-bit rows (8.6 GB) and 6-bit ones (2.9 GB); AES 4-bit rows (4.3 GB: the session's own algorithms hold most of the device)
         z, z2 = ("12", "3") if algo == 0 else ("5", "5")
-        for extra in ({"GSC_FEW_Z_GB": z}, {"GSC_FEW_Z_GB": "0"}, {"GSC_FEW_Z_GB": z, "GSC_FEW_COHERENT": "0", "GSC_FEW_WGS": "17"}, {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": z2}):
+        for extra in ({"GSC_FEW_Z_GB": z, "GSC_FEW_WIDE": "1"}, {"GSC_FEW_Z_GB": "0"}, {"GSC_FEW_Z_GB": z, "GSC_FEW_COHERENT": "0", "GSC_FEW_WGS": "17"},
+                      {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": z2, "GSC_FEW_WIDE": "1"}):
             assert _digest(dict(small, TEST_STATEMENTS=n, **extra), algo, pk_path) == base, (n, extra)
 
 
