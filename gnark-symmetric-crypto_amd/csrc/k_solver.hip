@@ -340,6 +340,34 @@ __device__ __forceinline__ fe pick_slot(const fe (&v)[FEW_SLOTS], uint32_t j) {
     return r;
 }
 
+// 1 / a for the latency kernel (a != 0, Montgomery in and out): binary extended Euclid on the limbs, ~25 k instructions instead of the
+// 128 k of Fermat's a^(r-2) (254 squarings on a lone wave: 0.43 ms, and AES-V2's log-derivative argument puts 400 divisions in a level).
+// Variable time, like gnark-crypto's Inverse; the batch kernel keeps the constant-shape power (its lanes hold different values).
+__device__ __noinline__ fe few_inverse(const fe& a_mont) {
+    fe u = a_mont, v, x1 = Fr::zero(), x2 = Fr::zero();       // invariants: x1 * a_mont = u, x2 * a_mont = v (mod r), as plain integers
+#pragma unroll
+    for (int i = 0; i < 8; i++) v.l[i] = FrParams::mod(i);
+    x1.l[0] = 1;
+    auto is_one = [](const fe& t) { uint32_t o = t.l[0] ^ 1u; for (int i = 1; i < 8; i++) o |= t.l[i]; return o == 0; };
+    auto shr1 = [](fe& t) { for (int i = 0; i < 7; i++) t.l[i] = (t.l[i] >> 1) | (t.l[i + 1] << 31); t.l[7] >>= 1; };
+    auto halve = [&](fe& t) {                                   // t / 2 mod r
+        if (t.l[0] & 1u) { uint64_t c = 0; for (int i = 0; i < 8; i++) { c += (uint64_t)t.l[i] + FrParams::mod(i); t.l[i] = (uint32_t)c; c >>= 32; } }      // t + r < 2^255
+        shr1(t);
+    };
+    auto geq = [](const fe& a, const fe& b) { for (int i = 7; i >= 0; i--) { if (a.l[i] != b.l[i]) return a.l[i] > b.l[i]; } return true; };
+    auto sub_plain = [](fe& a, const fe& b) { uint64_t br = 0; for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)a.l[i] - b.l[i] - br; a.l[i] = (uint32_t)d; br = (d >> 32) & 1; } };
+#pragma unroll 1
+    for (int it = 0; it < 1536 && !is_one(u) && !is_one(v); it++) {
+        if (!(u.l[0] & 1u)) { shr1(u); halve(x1); }
+        else if (!(v.l[0] & 1u)) { shr1(v); halve(x2); }
+        else if (geq(u, v)) { sub_plain(u, v); x1 = Fr::sub(x1, x2); }
+        else { sub_plain(v, u); x2 = Fr::sub(x2, x1); }
+    }
+    const fe r = is_one(u) ? x1 : x2;                           // (a R)^-1 as an integer
+    const fe r2 = Fr::r2();
+    return Fr::mul(r, Fr::mul(r2, r2));                         // * R^3 / R = a^-1 R
+}
+
 template <bool HAS_DIV>
 __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch& f, uint32_t i, uint32_t p, uint32_t lane, unsigned long long* stamps = nullptr) {
     const uint32_t w0 = f.d[0], w1 = f.d[1], w2 = f.d[2], w3 = f.d[3], toff = f.d[4], n0 = f.d[5], n1 = f.d[6], n2 = f.d[7];
@@ -462,7 +490,7 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
                 const fe known = loc == 1 ? vb : va;
                 fe part = loc == 1 ? va : vb;
                 if (Fr::is_zero(known)) { wire = Fr::zero(); bad = !Fr::eq(ab, vc); }
-                else if (HAS_DIV) { wire = Fr::sub(Fr::mul(vc, Fr::inv(known)), part); part = Fr::add(part, wire); }
+                else if (HAS_DIV) { wire = Fr::sub(Fr::mul(vc, few_inverse(known)), part); part = Fr::add(part, wire); }
                 else { wire = Fr::zero(); bad = true; }
                 if (loc == 1) va = part; else vb = part;
             }
