@@ -105,7 +105,7 @@ EngineConfig config_from_env() {
 // stream wait for the previous one's completion event (no host blocking).  Other processes on the same device are not covered —
 // there the kernel's bounded polling gives up and the call is solved again with one launch per level (prove_chunk).
 struct FewSolverChain { std::mutex m; hipEvent_t last = nullptr; };
-static FewSolverChain& few_solver_chain(int device) { static FewSolverChain chains[64]; return chains[device & 63]; }
+static FewSolverChain& few_solver_chain(int device) { static FewSolverChain* chains = new FewSolverChain[64]; return chains[device & 63]; }      // never destroyed: lanes may outlive static destructors
 
 class AlgorithmImpl {
   public:

@@ -11,6 +11,7 @@
 // puts ~2 400 waves on the chip per level; the kernel boundary is the barrier between levels.
 #include "kernels.hpp"
 #include "formats.hpp"
+#include <atomic>
 
 namespace gsc {
 using namespace bn254;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
 }
 
 // ---- calls with a handful of statements (single Prove): k_solver_few -----------------------------------------------------------------
-// With 1..8 statements in a 64-column batch, the lanes-are-proofs kernel above leaves the chip idle and pays, per level, a kernel
+// With a handful of statements (EngineConfig::few_max: up to 32) in a 64-column batch, the lanes-are-proofs kernel above leaves the chip idle and pays, per level, a kernel
 // launch, a cold walk through the instruction words and a lone wave's serial fold of every term (measured: 26 us per level, 163
 // levels for ChaCha20, 445 for AES).  Here the whole level range is ONE launch of a fixed grid that stays resident: a wave takes
 // one (statement, op) at a time with lanes = terms of its linear expressions (one load round, one Montgomery product, a short
@@ -713,10 +714,15 @@ void launch_solver_few(const SolverFewArgs& a, int has_div, uint32_t workgroups,
     // 96 KiB of (unused) dynamic LDS: more than half of a CU's 160 KiB, so that no two workgroups share a CU and every wave has a
     // SIMD nearly to itself — the level time is the longest op's serial instruction stream
     constexpr size_t lds = 96 * 1024;
-    static const bool attr = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_solver_few<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(k_solver_few<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-    }();
+    static std::atomic<int> state[64];                       // per device (function attributes are per device): 0 not asked yet, 1 granted, 2 refused
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::atomic<int>& st = state[dev & 63];
+    if (st.load() == 0) {
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solver_few<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_solver_few<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        st.store(ok ? 1 : 2);
+    }
+    const bool attr = st.load() == 1;
     const size_t dyn = attr ? lds : 0;
     if (has_div) hipLaunchKernelGGL(k_solver_few<true>, dim3(workgroups), dim3(64 * FEW_WAVES), dyn, s, a);
     else hipLaunchKernelGGL(k_solver_few<false>, dim3(workgroups), dim3(64 * FEW_WAVES), dyn, s, a);
