@@ -807,7 +807,7 @@ class AlgorithmImpl {
         // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
         NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
         HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
-        HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream));
+        HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, ln.n_real <= (size_t)cfg.few_max && cfg.few_path ? ln.n_real : 0));      // latency path: the statements' columns only
         HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
         if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
         // 3. MSMs.  A and B1 first: the two scalar multiplications of the assembly only need those two sums and run on a side stream

@@ -306,11 +306,12 @@ __global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, co
 
 }  // namespace
 
-hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s) {
+hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols) {
     const int L = p.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     if (L < NTT_MIN_LOG2 || L > NTT_MAX_LOG2 || batch % P) return hipErrorInvalidValue;      // block sizes / launch bounds below assume this range
     const unsigned G = 1u << Lhi, Cn = 1u << Llo;
-    const unsigned pb = (unsigned)(batch / P);
+    if (ncols > batch) return hipErrorInvalidValue;
+    const unsigned pb = (unsigned)((ncols ? (ncols + P - 1) / P * P : batch) / P);      // groups of P columns that are transformed
     const size_t lds_s = (size_t)G * P * 36, lds_c = (size_t)Cn * P * 36;      // nine 32-bit limb planes per element
     hipError_t e = hipSuccess;
     auto opt_in = [&](const void* f, size_t lds) { if (e == hipSuccess && lds > 65536) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };

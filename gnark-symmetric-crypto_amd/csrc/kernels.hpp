@@ -90,7 +90,8 @@ constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_
 // Domains the four kernels are written (and tested) for: workgroups of 2^ceil(L/2) and 2^floor(L/2) threads within their launch bounds.
 constexpr int NTT_MIN_LOG2 = 15, NTT_MAX_LOG2 = 17;
 // Returns the first launch-configuration error (nothing is launched when the domain is unsupported).
-hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s);
+// ncols > 0: only the first ncols columns (rounded up to the tile's 4) are transformed — a call with a handful of statements in a 64-column batch
+hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols = 0);
 
 // ---- multi-scalar multiplication (k_msm_win.hip, k_msm.hip) ----
 // Every MSM of the prover is a fixed-base sum over a set of the proving key (A, B1, B2, K, Z, commitment bases) for a batch of
