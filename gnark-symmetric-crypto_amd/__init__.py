@@ -20,7 +20,7 @@ CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
 ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
 
 EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw", "gsc_setup",
-           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_msm_z_kernel_ms", "gsc_debug_field_ops", "gsc_debug_compute_h"]
+           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_msm_z_kernel_ms", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_glv_split"]
 
 
 class GoSlice(C.Structure):
@@ -208,6 +208,18 @@ def debug_field_ops(field: int, op: int, a, b, chain=1):
     if rc:
         raise RuntimeError("gsc_debug_field_ops failed")
     return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+
+
+def debug_glv_split(k: int):
+    """TEST HOOK (host arithmetic, no GPU): k -> (k1, k2) with k = k1 + k2 * lambda (mod r), the split of csrc/glv.hpp."""
+    L = lib()
+    L.gsc_debug_glv_split.restype = C.c_int
+    L.gsc_debug_glv_split.argtypes = [C.c_char_p, C.c_void_p]
+    out = C.create_string_buffer(44)
+    if L.gsc_debug_glv_split(int(k).to_bytes(32, "little"), out) != 0:
+        raise RuntimeError("gsc_debug_glv_split failed")
+    k1 = int.from_bytes(out.raw[:20], "little"); k2 = int.from_bytes(out.raw[20:40], "little"); neg = out.raw[40]
+    return (-k1 if neg & 1 else k1), (-k2 if neg & 2 else k2)
 
 
 def debug_compute_h(algorithm_id: int, abc_be: bytes, m: int) -> bytes:

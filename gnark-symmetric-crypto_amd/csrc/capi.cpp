@@ -6,6 +6,7 @@
 // {"proof":{"proofJson"},"publicSignals"} output, and "panic -> JSON" error reporting.
 #include "../../include/libprove.h"
 #include "engine.hpp"
+#include "glv.hpp"
 #include "host_ciphers.hpp"
 #include "json.hpp"
 #include "setup.hpp"
@@ -415,6 +416,14 @@ int gsc_debug_field_ops(int field, int op, const uint8_t* a, const uint8_t* b, u
     catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
 }
 
+int gsc_debug_glv_split(const uint8_t* k, uint8_t* out) {
+    if (hooks_refused("gsc_debug_glv_split") || !k || !out) return -1;
+    uint32_t w[8]; memcpy(w, k, 32);
+    GlvSplit s;
+    if (!glv_split(w, s)) return -1;
+    memcpy(out, s.k1, 20); memcpy(out + 20, s.k2, 20); memcpy(out + 40, &s.neg, 4);
+    return 0;
+}
 long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t* abc_be, size_t m, uint8_t* h_out, size_t cap) {
     if (hooks_refused("gsc_debug_compute_h") || algorithmID > 2) return -1;
     Algorithm* a = lookup(algorithmID); if (!a) return -1;

@@ -147,7 +147,7 @@ class AlgorithmImpl {
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
         size_t cap = 0;
-        DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync;
+        DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync; DevBuf<GlvSplit> d_glv;
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
@@ -523,7 +523,7 @@ class AlgorithmImpl {
         for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
-        ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2);
+        ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2); ln.d_glv.alloc(2 * MSM_FEW_PROOFS);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
         // calls with a handful of statements (k_solver_few) write their own columns only: the others must always hold field elements
         // (zero, later whatever an earlier call left there) because the transforms and MSMs run over whole 64-column batches
@@ -709,6 +709,15 @@ class AlgorithmImpl {
         std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs, n, B, h_in, h_rs);
         ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
         ln.d_rs.upload(h_rs.data(), h_rs.size(), ln.stream);
+        std::vector<GlvSplit> h_glv;                                     // (lives as long as the other staging vectors of the call)
+        if (n <= (size_t)cfg.few_max && cfg.few_path && B == 64) {      // latency path: the two halves of s and r for k_fin_scalarmul_few
+            h_glv.resize(2 * n);
+            for (size_t i = 0; i < n; i++) for (int role = 0; role < 2; role++) {
+                uint32_t w[8]; memcpy(w, h_rs.data() + 64 * i + (role == 0 ? 32 : 0), 32);
+                if (!glv_split(w, h_glv[2 * i + role])) throw std::runtime_error("internal: scalar split out of range");
+            }
+            ln.d_glv.upload(h_glv.data(), h_glv.size(), ln.stream);
+        }
         HIP_CHECK(hipMemsetAsync(ln.d_flags.p, 0, ln.d_flags.bytes(), ln.stream));
         HIP_CHECK(hipEventRecord(ln.ev[0], ln.stream));
         // 1. witness
@@ -796,7 +805,7 @@ class AlgorithmImpl {
             HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
             run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p, false, true);
             run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p, false, true);
-            launch_fin_scalarmul_few(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.n_real, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
+            launch_fin_scalarmul_few(ln.d_sumA.p, ln.d_sumB1.p, ln.d_glv.p, B, ln.n_real, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
         }
         const bool early_b2 = early_ab && mB2.latency_flat();         // the G2 sum too (it only reads the witness): a third stream
         if (early_b2) {

@@ -138,38 +138,57 @@ __global__ __launch_bounds__(64) void k_fin_scalarmul(const G1Xyzz* sumA, const 
     }
     G1x::store_xyzz(reinterpret_cast<fe*>(tmp) + ((size_t)role * batch + p) * 4, acc);
 }
-// The same for calls with a handful of statements: one WAVE per (statement, role).  The scalar is cut into 64 four-bit chunks, lane q
-// owns chunk q: all lanes walk the one doubling chain 2^i * A together (252 doublings, nothing else on it), lane q keeps 2^(4q) * A when
-// the chain passes it, multiplies it by its chunk (4 doublings, <= 4 additions) and a butterfly adds the 64 pieces up.  252 doublings +
-// 14 additions on the critical path instead of 254 + ~127: the longest serial chain of a single Prove, 2.3 -> 1.5 ms.
-__global__ __launch_bounds__(64) void k_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch,
+// The same for calls with a handful of statements: one WAVE per (statement, role), and the scalar split in two halves by the curve's
+// endomorphism (glv.hpp: k = k1 + k2 lambda, k A = k1 A + k2 phi(A), phi(x, y) = (beta x, y)).  Each half is cut into 26 five-bit
+// chunks; lanes 0..25 own the chunks of k1, lanes 32..57 those of k2: all lanes walk the ONE doubling chain 2^i A together (125
+// doublings, nothing else on it), a lane keeps 2^(5q) A when the chain passes it (the k2 lanes apply phi: one product), multiplies it
+// by its chunk (5 doublings, <= 5 additions) and a butterfly adds the pieces up.  125 doublings + 16 additions on the critical
+// path instead of 254 + ~127: the longest serial chain of a single Prove, 2.3 -> 0.9 ms.
+__global__ __launch_bounds__(64) void k_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const GlvSplit* glv, size_t batch,
                                                            G1Xyzz* tmp, uint8_t* out, uint8_t* flags) {
+    using F = Fp29f;
     const size_t p = blockIdx.x;
     const int role = blockIdx.y;
     const uint32_t lane = threadIdx.x;
     const fe* src = reinterpret_cast<const fe*>(role == 0 ? sumA : sumB1) + 4 * p;
-    const Xyzz9<Fp29f> P = G1x::load_xyzz(src);
-    const uint32_t* sc = reinterpret_cast<const uint32_t*>(rs + 64 * p) + (role == 0 ? 8 : 0);   // role 0 uses s, role 1 uses r
-    Xyzz9<Fp29f> acc = G1x::infinity();
+    const Xyzz9<F> P = G1x::load_xyzz(src);
+    const GlvSplit* g = glv + 2 * p + role;                  // role 0: s, role 1: r
+    Xyzz9<F> acc = G1x::infinity();
     if (!P.inf) {                                            // (wave-uniform)
-        const Aff9<Fp29f> A = G1x::to_aff(P);
+        const Aff9<F> A = G1x::to_aff(P);
         if (role == 0 && lane == 0) { store_canon(out + 256 * p, A.x); store_canon(out + 256 * p + 32, A.y); }
-        Xyzz9<Fp29f> R = G1x::from_aff(A), mine = R;
+        const bool second = lane >= 32;
+        const uint32_t q = lane & 31;
+        Xyzz9<F> R = G1x::from_aff(A), mine = R;
 #pragma unroll 1
-        for (uint32_t i = 0; i < 252; i++) {
+        for (uint32_t i = 0; i < 125; i++) {
             R = G1x::dbl(R);
-            const bool take = 4 * lane == i + 1;
+            const bool take = 5 * q == i + 1;
             mine.x = take ? R.x : mine.x; mine.y = take ? R.y : mine.y; mine.zz = take ? R.zz : mine.zz; mine.zzz = take ? R.zzz : mine.zzz;
         }
-        const uint32_t chunk = (sc[lane >> 3] >> (4 * (lane & 7))) & 15u;
+        {
+            fe bw = {};                                      // beta, canonical
+            bw.l[0] = 0x77fffffeu; bw.l[1] = 0x57634731u; bw.l[2] = 0xacdb5c4fu; bw.l[3] = 0xd4f263f1u; bw.l[4] = 0xa0d48bacu; bw.l[5] = 0x59e26bceu;
+            const fe9 bx = F::mul(mine.x, Fp29::to_mont(Fp29::unpack(bw)));
+            mine.x = second ? bx : mine.x;
+        }
+        const uint32_t* kw = second ? g->k2 : g->k1;
+        if ((g->neg >> (second ? 1 : 0)) & 1u) mine.y = F::norm(F::neg(mine.y));
+        uint32_t chunk = 0;
+        if (q < 26) {
+            const uint32_t o = 5 * q, w = o >> 5, sh = o & 31;
+            chunk = kw[w] >> sh;
+            if (sh > 27) chunk |= kw[w + 1] << (32 - sh);    // (w + 1 <= 4)
+            chunk &= 31u;
+        }
 #pragma unroll 1
-        for (int b = 3; b >= 0; b--) {
+        for (int b = 4; b >= 0; b--) {
             acc = G1x::dbl(acc);
-            const Xyzz9<Fp29f> t = G1x::add(acc, mine);
+            const Xyzz9<F> t = G1x::add(acc, mine);
             if ((chunk >> b) & 1u) acc = t;
         }
         for (int m = 32; m >= 1; m >>= 1) {
-            Xyzz9<Fp29f> o;
+            Xyzz9<F> o;
             o.x = shfl_xor_e(acc.x, m); o.y = shfl_xor_e(acc.y, m); o.zz = shfl_xor_e(acc.zz, m); o.zzz = shfl_xor_e(acc.zzz, m);
             o.inf = __shfl_xor((int)acc.inf, m) != 0;
             acc = G1x::add(acc, o);
@@ -320,8 +339,8 @@ void launch_challenge_from_point(const uint8_t* cpts, fe* commit, size_t batch, 
 void launch_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
     hipLaunchKernelGGL(k_fin_scalarmul, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumA, sumB1, rs, batch, tmp, out, flags);
 }
-void launch_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch, size_t nproofs, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
-    hipLaunchKernelGGL(k_fin_scalarmul_few, dim3((unsigned)nproofs, 2), dim3(64), 0, s, sumA, sumB1, rs, batch, tmp, out, flags);
+void launch_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const GlvSplit* glv, size_t batch, size_t nproofs, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
+    hipLaunchKernelGGL(k_fin_scalarmul_few, dim3((unsigned)nproofs, 2), dim3(64), 0, s, sumA, sumB1, glv, batch, tmp, out, flags);
 }
 void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s) {
     hipLaunchKernelGGL(k_fin_combine, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumB2, sumK, sumZ, tmp, batch, out, flags);

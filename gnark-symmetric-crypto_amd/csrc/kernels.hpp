@@ -1,6 +1,7 @@
 // Launchers for the gfx950 kernels (defined in k_*.hip).  Everything takes a stream and returns
 // immediately; no launcher allocates, synchronises or copies (hipGraph-capturable, guide §6 G9).
 #pragma once
+#include "glv.hpp"
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstddef>
@@ -227,8 +228,9 @@ void launch_challenge_from_point(const uint8_t* cpts, fe* commit, size_t batch, 
 // Two kernels: the scalar multiplications s * Ar and r * Bs1 (254 doublings each: the longest serial chain of the assembly) only need
 // sumA and sumB1, so they can run beside the remaining MSMs; the combine step needs everything.
 void launch_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s);
-// the same for the first nproofs columns only, one wave per (statement, role): lanes share the doubling chain and split the scalar
-void launch_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t* rs, size_t batch, size_t nproofs, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s);
+// the same for the first nproofs columns only, one wave per (statement, role): lanes share the doubling chain and split the two GLV
+// halves of the scalar (glv[2 * proof + role], role 0 = s, role 1 = r: glv.hpp glv_split on the host)
+void launch_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const GlvSplit* glv, size_t batch, size_t nproofs, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s);
 void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s);
 
 }  // namespace gsc

@@ -86,6 +86,10 @@ extern int gsc_debug_field_ops(int field, int op, const uint8_t *a, const uint8_
  * h_out (cap bytes, at least domain*64*32): [domain][64] canonical little-endian values, row k = coefficient bitrev(k).
  * Returns the domain size (also when h_out is NULL: size query), -1 on error. */
 extern long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t *abc_be, size_t m, uint8_t *h_out, size_t cap);
+/* TEST HOOK (host arithmetic only, no GPU): the GLV split the latency path feeds to its scalar multiplications
+ * (csrc/glv.hpp).  k: canonical scalar < r, 32 bytes little-endian.  out: 20 bytes |k1|, 20 bytes |k2| (little-endian), 4 bytes
+ * flags (bit 0: k1 < 0, bit 1: k2 < 0) with k = k1 + k2 * lambda (mod r).  Returns 0, -1 on error. */
+extern int gsc_debug_glv_split(const uint8_t *k, uint8_t *out);
 
 /* Human-readable description of an initialised algorithm (sizes, table memory); returns bytes written. */
 extern size_t gsc_describe(GoUint8 algorithmID, char *out, size_t cap);
