@@ -432,6 +432,18 @@ FewProgram build_few_program(const SolverProgram& sp) {
         const uint32_t d[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
         fp.ops.insert(fp.ops.end(), d, d + 8);
     };
+    auto r1c = [&](uint32_t at) {
+        const uint32_t toff = (uint32_t)(fp.terms.size() / 2);
+        uint32_t q = at + 5;
+        const uint32_t nl = expr(q), nr = expr(q), no = expr(q);
+        desc(OP_R1C | (W[at + 1] << 8), W[at + 2], W[at + 3], W[at + 4], toff, nl, nr, no);
+    };
+    // Constraints that solve nothing (loc = 0: more than half of the ops, ChaCha20's 130-term add32 checks among them) only read wires
+    // and write their A / B / C rows: no later op waits for them, so they leave the dependent chain of levels and run at the very
+    // end, where thousands of them fill the grid (a failed check still marks the statement unsatisfied).
+    uint32_t last_generic = nlev;
+    for (uint32_t l = 0; l < nlev; l++) if (!sp.level_kind[l]) last_generic = l;
+    std::vector<uint32_t> deferred;
     for (uint32_t l = 0; l < nlev; l++) {
         fp.level_start.push_back((uint32_t)(fp.ops.size() / 8));
         if (sp.level_kind[l]) continue;
@@ -439,9 +451,7 @@ FewProgram build_few_program(const SolverProgram& sp) {
             const uint32_t at = ops[i], op = W.at(at) & 0xFF;
             const uint32_t toff = (uint32_t)(fp.terms.size() / 2);
             if (op == OP_R1C) {
-                uint32_t q = at + 5;
-                const uint32_t nl = expr(q), nr = expr(q), no = expr(q);
-                desc(OP_R1C | (W[at + 1] << 8), W[at + 2], W[at + 3], W[at + 4], toff, nl, nr, no);
+                if (W[at + 1] == 0 && l != last_generic) deferred.push_back(at); else r1c(at);
             } else if (op == OP_NBITS) {
                 uint32_t q = at + 3;
                 const uint32_t n = expr(q);
@@ -454,6 +464,11 @@ FewProgram build_few_program(const SolverProgram& sp) {
                 }
             } else if (op == OP_RANDOMIZE || op == OP_COMMIT) desc(op, W[at + 1], W[at + 2], 0, 0, 0, 0, 0);
             else throw std::runtime_error("solver: op " + std::to_string(op) + " in a generic level");
+        }
+        if (l == last_generic) {                      // longest first: they set the tail of the last round
+            std::stable_sort(deferred.begin(), deferred.end(), [&](uint32_t x, uint32_t y) { return (W[x] >> 8) > (W[y] >> 8); });
+            for (uint32_t at : deferred) r1c(at);
+            deferred.clear();
         }
         const size_t w = fp.ops.size() / 8 - fp.level_start.back();
         if (w > fp.max_level_width) fp.max_level_width = w;
