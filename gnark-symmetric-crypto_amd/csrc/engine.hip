@@ -129,6 +129,7 @@ class AlgorithmImpl {
 
     // program
     DevBuf<uint32_t> prog, sched, lookup_coeff; DevBuf<fe> coeff, coeff_inv;
+    DevBuf<uint32_t> few_count_ops, few_count_qoff; std::vector<uint32_t> few_count_first;
     DevBuf<uint32_t> few_ops, few_terms, few_lstart;          // the same program laid out for k_solver_few (formats.hpp FewProgram)
     uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; std::vector<uint32_t> level_long; int has_div = 0;
     // NTT
@@ -216,6 +217,9 @@ class AlgorithmImpl {
             few_ops.alloc(fp.ops.size() ? fp.ops.size() : 8); few_terms.alloc(fp.terms.size()); few_lstart.alloc(fp.level_start.size());
             if (!fp.ops.empty()) few_ops.upload(fp.ops.data(), fp.ops.size(), stream);
             few_terms.upload(fp.terms.data(), fp.terms.size(), stream); few_lstart.upload(fp.level_start.data(), fp.level_start.size(), stream);
+            few_count_first = fp.count_first;
+            few_count_ops.alloc(fp.count_ops.size() + 4); few_count_qoff.alloc(fp.count_qoff.size() + 1);
+            if (!fp.count_ops.empty()) { few_count_ops.upload(fp.count_ops.data(), fp.count_ops.size(), stream); few_count_qoff.upload(fp.count_qoff.data(), fp.count_qoff.size(), stream); }
         }
         lookup_coeff.alloc(sp.lookup_coeff.size() ? sp.lookup_coeff.size() : 1);
         if (!sp.lookup_coeff.empty()) lookup_coeff.upload(sp.lookup_coeff.data(), sp.lookup_coeff.size(), stream);
@@ -747,8 +751,10 @@ class AlgorithmImpl {
         auto run_levels = [&](uint32_t from, uint32_t to) {
             for (uint32_t l = from; l < to; l++) {
                 sa.first_level = l; sa.n_long = level_long[l];
-                if (level_kind[l]) launch_solver_count_level(sa, level_width[l], ln.stream);
-                else if (few_solver) {                   // a run of generic levels: one launch, device-wide barriers in between
+                if (level_kind[l]) {
+                    if (few_solver) launch_solver_count_few(sa, few_count_ops.p, few_count_qoff.p, few_count_first[l], level_width[l], n, ln.stream);
+                    else launch_solver_count_level(sa, level_width[l], ln.stream);
+                } else if (few_solver) {                   // a run of generic levels: one launch, device-wide barriers in between
                     uint32_t e = l + 1; while (e < to && !level_kind[e]) e++;
                     fa.from = l; fa.to = e; fa.trace = sa.trace;
                     HIP_CHECK(hipMemsetAsync(ln.d_fsync.p, 0, 4, ln.stream));

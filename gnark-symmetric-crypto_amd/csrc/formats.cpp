@@ -446,7 +446,17 @@ FewProgram build_few_program(const SolverProgram& sp) {
     std::vector<uint32_t> deferred;
     for (uint32_t l = 0; l < nlev; l++) {
         fp.level_start.push_back((uint32_t)(fp.ops.size() / 8));
-        if (sp.level_kind[l]) continue;
+        fp.count_first.push_back((uint32_t)(fp.count_ops.size() / 4));
+        if (sp.level_kind[l]) {                        // histogram ops: where every query starts
+            for (uint32_t i = lstart[l]; i < lstart[l + 1]; i++) {
+                const uint32_t at = ops[i], ntab = W.at(at + 2), nq = W.at(at + 4);
+                const uint32_t d[4] = {at, (uint32_t)fp.count_qoff.size(), nq, 0};
+                fp.count_ops.insert(fp.count_ops.end(), d, d + 4);
+                uint32_t q = at + 5 + 6 * ntab;
+                for (uint32_t k = 0; k < nq; k++) { fp.count_qoff.push_back(q); q += 1 + 2 * W.at(q); q += 1 + 2 * W.at(q); }
+            }
+            continue;
+        }
         for (uint32_t i = lstart[l]; i < lstart[l + 1]; i++) {
             const uint32_t at = ops[i], op = W.at(at) & 0xFF;
             const uint32_t toff = (uint32_t)(fp.terms.size() / 2);
@@ -474,6 +484,7 @@ FewProgram build_few_program(const SolverProgram& sp) {
         if (w > fp.max_level_width) fp.max_level_width = w;
     }
     fp.level_start.push_back((uint32_t)(fp.ops.size() / 8));
+    fp.count_first.push_back((uint32_t)(fp.count_ops.size() / 4));
     fp.ops.insert(fp.ops.end(), 8, 0u);                 // one all-zero descriptor past the end (a wave without work may fetch it)
     fp.terms.insert(fp.terms.end(), 2 * 256, 0u);       // a lane may fetch (not use) up to 3 x 64 pairs past an op's last term
     return fp;

@@ -101,6 +101,9 @@ struct FewProgram {
     std::vector<uint32_t> terms;         // (coefficient id, wire id) pairs
     std::vector<uint32_t> level_start;
     size_t max_level_width = 0;
+    // OP_COUNT levels for k_solver_count_few (lanes = queries): per op [word offset of the op, first entry in count_qoff, queries, 0];
+    // count_qoff: word offset of every query's first expression; count_first[l]: first op of level l in count_ops (OP_COUNT levels only)
+    std::vector<uint32_t> count_ops, count_qoff, count_first;
 };
 FewProgram build_few_program(const SolverProgram& sp);
 

@@ -75,6 +75,8 @@ struct SolverFewArgs {
 void launch_solver_few(const SolverFewArgs& a, int has_div, uint32_t workgroups, hipStream_t s);
 // same for a level made of OP_COUNT ops (LDS histogram kernel)
 void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
+// the same for the first nproofs columns of a latency-path call: lanes = queries (FewProgram::count_ops / count_qoff; first_op = count_first[level])
+void launch_solver_count_few(const SolverArgs& a, const uint32_t* count_ops, const uint32_t* count_qoff, uint32_t first_op, uint32_t level_width, size_t nproofs, hipStream_t s);
 // *flag |= 1 if some OP_COUNT table's index column is not 0,1,2,... (InitAlgorithm-time validation)
 void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s);
 
