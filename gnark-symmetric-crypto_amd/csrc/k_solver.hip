@@ -341,32 +341,38 @@ __device__ __forceinline__ fe pick_slot(const fe (&v)[FEW_SLOTS], uint32_t j) {
     return r;
 }
 
-// 1 / a for the latency kernel (a != 0, Montgomery in and out): binary extended Euclid on the limbs, ~25 k instructions instead of the
-// 128 k of Fermat's a^(r-2) (254 squarings on a lone wave: 0.43 ms, and AES-V2's log-derivative argument puts 400 divisions in a level).
-// Variable time, like gnark-crypto's Inverse; the batch kernel keeps the constant-shape power (its lanes hold different values).
+// 1 / a for the latency kernel (a != 0, Montgomery in and out): Kaliski's almost-inverse — a binary Euclid whose cofactors are only
+// shifted and added, never reduced, giving (a R)^-1 2^k with 254 <= k <= 508 — followed by 512 - k modular doublings:
+// (a R)^-1 2^k 2^(512-k) = a^-1 R.  ~25 k instructions instead of the 128 k of Fermat's a^(r-2) (254 squarings on a lone wave:
+// 0.43 ms, and AES-V2's log-derivative argument puts 400 divisions in a level).  Variable time, like gnark-crypto's Inverse; the
+// batch kernel keeps the constant-shape power (its lanes hold different values).
 __device__ __noinline__ fe few_inverse(const fe& a_mont) {
-    fe u = a_mont, v, x1 = Fr::zero(), x2 = Fr::zero();       // invariants: x1 * a_mont = u, x2 * a_mont = v (mod r), as plain integers
+    fe u, v = a_mont, r = Fr::zero(), s = Fr::zero();
 #pragma unroll
-    for (int i = 0; i < 8; i++) v.l[i] = FrParams::mod(i);
-    x1.l[0] = 1;
-    auto is_one = [](const fe& t) { uint32_t o = t.l[0] ^ 1u; for (int i = 1; i < 8; i++) o |= t.l[i]; return o == 0; };
+    for (int i = 0; i < 8; i++) u.l[i] = FrParams::mod(i);
+    s.l[0] = 1;
     auto shr1 = [](fe& t) { for (int i = 0; i < 7; i++) t.l[i] = (t.l[i] >> 1) | (t.l[i + 1] << 31); t.l[7] >>= 1; };
-    auto halve = [&](fe& t) {                                   // t / 2 mod r
-        if (t.l[0] & 1u) { uint64_t c = 0; for (int i = 0; i < 8; i++) { c += (uint64_t)t.l[i] + FrParams::mod(i); t.l[i] = (uint32_t)c; c >>= 32; } }      // t + r < 2^255
-        shr1(t);
-    };
-    auto geq = [](const fe& a, const fe& b) { for (int i = 7; i >= 0; i--) { if (a.l[i] != b.l[i]) return a.l[i] > b.l[i]; } return true; };
+    auto shl1 = [](fe& t) { for (int i = 7; i > 0; i--) t.l[i] = (t.l[i] << 1) | (t.l[i - 1] >> 31); t.l[0] <<= 1; };
+    auto gt = [](const fe& a, const fe& b) { for (int i = 7; i >= 0; i--) { if (a.l[i] != b.l[i]) return a.l[i] > b.l[i]; } return false; };
     auto sub_plain = [](fe& a, const fe& b) { uint64_t br = 0; for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)a.l[i] - b.l[i] - br; a.l[i] = (uint32_t)d; br = (d >> 32) & 1; } };
+    auto add_plain = [](fe& a, const fe& b) { uint64_t c = 0; for (int i = 0; i < 8; i++) { c += (uint64_t)a.l[i] + b.l[i]; a.l[i] = (uint32_t)c; c >>= 32; } };      // cofactors stay below 2 r < 2^255
+    uint32_t k = 0;
 #pragma unroll 1
-    for (int it = 0; it < 1536 && !is_one(u) && !is_one(v); it++) {
-        if (!(u.l[0] & 1u)) { shr1(u); halve(x1); }
-        else if (!(v.l[0] & 1u)) { shr1(v); halve(x2); }
-        else if (geq(u, v)) { sub_plain(u, v); x1 = Fr::sub(x1, x2); }
-        else { sub_plain(v, u); x2 = Fr::sub(x2, x1); }
+    while (!Fr::is_zero(v) && k < 512) {
+        if (!(u.l[0] & 1u)) { shr1(u); shl1(s); }
+        else if (!(v.l[0] & 1u)) { shr1(v); shl1(r); }
+        else if (gt(u, v)) { sub_plain(u, v); shr1(u); add_plain(r, s); shl1(s); }
+        else { sub_plain(v, u); shr1(v); add_plain(s, r); shl1(r); }
+        k++;
     }
-    const fe r = is_one(u) ? x1 : x2;                           // (a R)^-1 as an integer
-    const fe r2 = Fr::r2();
-    return Fr::mul(r, Fr::mul(r2, r2));                         // * R^3 / R = a^-1 R
+    fe m;
+#pragma unroll
+    for (int i = 0; i < 8; i++) m.l[i] = FrParams::mod(i);
+    if (!gt(m, r)) sub_plain(r, m);                             // r < 2 r_mod
+    fe x = Fr::neg(r);                                          // r_mod - r = (a R)^-1 2^k
+#pragma unroll 1
+    for (uint32_t i = k; i < 512; i++) x = Fr::dbl(x);
+    return x;
 }
 
 template <bool HAS_DIV>
