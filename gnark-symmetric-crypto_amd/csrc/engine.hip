@@ -168,8 +168,8 @@ class AlgorithmImpl {
     size_t cap = 0;                     // proofs per lane = the largest chunk
 
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf) : cipher(c), cfg(cf) {
-        // measured crossover with the batch kernels (one 64-column batch: 12.9 ms ChaCha20, 43 ms AES): 32 statements for ChaCha20 (11.4 ms), ~15 for AES (15 ms + 1.9 ms each)
-        if (!cfg.few_max) cfg.few_max = cipher == CHACHA20 ? 32 : 12;
+        // measured crossover with the batch kernels (one 64-column batch: 12.9 ms ChaCha20, 43.7 ms AES): 32 statements for ChaCha20 (10.2 ms), ~23 for AES (8.2 ms + 1.6 ms each: 38.4 ms for 20)
+        if (!cfg.few_max) cfg.few_max = cipher == CHACHA20 ? 32 : 20;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the GPU prover has no CPU fallback");
         HIP_CHECK(hipSetDevice(cfg.device));
