@@ -39,7 +39,7 @@ struct EngineConfig {
     int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no prediction-based layout; 1 bit groups / row lengths from a calibration witness; 2 every wire predicted a bit (test: exercises the fallbacks)
     int row_margin_bits = 1;     // GSC_ROW_MARGIN_BITS: a wire seen with k-bit values gets a row of 2^(k + margin) multiples (capped at 2^(c-1))
     size_t win_slice = 256;      // GSC_WIN_SLICE: bases per slice of the windowed MSM kernel at full batches (measured 64 .. 512: kernel time within 1 %)
-    int few_path = 1;            // GSC_FEW_PATH: calls with at most 8 statements use the lanes-are-bases MSM kernel (latency path); 0 = always the batch kernel
+    int few_path = 1;            // GSC_FEW_PATH: calls with at most few_max statements use the latency kernels for the MSMs, the quotient and the assembly; 0 = always the batch kernels
     int few_max = 0;             // GSC_FEW_MAX: the largest call the latency kernels take (<= MSM_FEW_PROOFS = 32); 0 = 32 for ChaCha20 (4.6 ms for 1 statement, 7.8 ms for 16, 11.3 ms for 32; the batch kernels need 12.3 ms for anything up to 64), 20 for AES (8.2 ms for 1, +1.6 ms each: 38.4 ms for 20; batch kernels 43.7 ms)
     int few_solver = 1;          // GSC_FEW_SOLVER: such calls also solve the witness with the resident lanes-are-terms kernel (k_solver_few); 0 = one launch per level
     int few_workgroups = 0;      // GSC_FEW_WGS: its grid (workgroups of 8 waves, one per CU, so all are resident); 0 = 128 for 1-2 statements, 256 beyond

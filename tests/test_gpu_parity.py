@@ -241,7 +241,7 @@ def test_engine_options_do_not_change_the_proofs_aes(aes_keys):
 
 @pytest.mark.parametrize("algo,counts", [(0, ("1", "5")), (1, ("3",))])
 def test_latency_path_options_do_not_change_the_proofs(aes_keys, algo, counts):
-    # Calls with at most 8 statements take kernels of their own (resident lanes-are-terms solver with device-wide barriers, flat and
+    # Calls with a handful of statements (GSC_FEW_MAX: 32 ChaCha20, 20 AES) take kernels of their own (resident lanes-are-terms solver with device-wide barriers, flat and
     # windowed MSMs with lanes = bases, the quotient bases as (base, window) rows without a Horner pass, A / B1 sums early on the side
     # stream).  With (r, s, mask) fixed, a handful of statements must give the same bytes as the batch kernels (GSC_FEW_PATH=0
     # GSC_FEW_SOLVER=0), whatever the grid, the barrier's memory mode, the quotient layout and the latency rows of the wide wires (GSC_FEW_WIDE).
