@@ -143,23 +143,29 @@ __global__ __launch_bounds__(64) void k_fin_scalarmul(const G1Xyzz* sumA, const 
 // chunks; lanes 0..25 own the chunks of k1, lanes 32..57 those of k2: all lanes walk the ONE doubling chain 2^i A together (125
 // doublings, nothing else on it), a lane keeps 2^(5q) A when the chain passes it (the k2 lanes apply phi: one product), multiplies it
 // by its chunk (5 doublings, <= 5 additions) and a butterfly adds the pieces up.  125 doublings + 16 additions on the critical
-// path instead of 254 + ~127: the longest serial chain of a single Prove, 2.3 -> 0.9 ms.
+// path instead of 254 + ~127 (and no field inversion: the chain starts from the XYZZ sum, a third wave turns Ar into the affine
+// form the proof carries): the longest serial chain of a single Prove, 2.3 -> 0.6 ms.
 __global__ __launch_bounds__(64) void k_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const GlvSplit* glv, size_t batch,
                                                            G1Xyzz* tmp, uint8_t* out, uint8_t* flags) {
     using F = Fp29f;
     const size_t p = blockIdx.x;
     const int role = blockIdx.y;
     const uint32_t lane = threadIdx.x;
-    const fe* src = reinterpret_cast<const fe*>(role == 0 ? sumA : sumB1) + 4 * p;
+    const fe* src = reinterpret_cast<const fe*>(role == 1 ? sumB1 : sumA) + 4 * p;
     const Xyzz9<F> P = G1x::load_xyzz(src);
+    if (role == 2) {                                         // the proof's Ar in affine form: a field inversion (0.28 ms) that the chains need not wait for
+        if (lane == 0) {
+            if (!P.inf) { const Aff9<F> A = G1x::to_aff(P); store_canon(out + 256 * p, A.x); store_canon(out + 256 * p + 32, A.y); }
+            else atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), 1u << (8 * (p & 3)));
+        }
+        return;
+    }
     const GlvSplit* g = glv + 2 * p + role;                  // role 0: s, role 1: r
     Xyzz9<F> acc = G1x::infinity();
     if (!P.inf) {                                            // (wave-uniform)
-        const Aff9<F> A = G1x::to_aff(P);
-        if (role == 0 && lane == 0) { store_canon(out + 256 * p, A.x); store_canon(out + 256 * p + 32, A.y); }
         const bool second = lane >= 32;
         const uint32_t q = lane & 31;
-        Xyzz9<F> R = G1x::from_aff(A), mine = R;
+        Xyzz9<F> R = P, mine = R;
 #pragma unroll 1
         for (uint32_t i = 0; i < 125; i++) {
             R = G1x::dbl(R);
@@ -193,8 +199,6 @@ __global__ __launch_bounds__(64) void k_fin_scalarmul_few(const G1Xyzz* sumA, co
             o.inf = __shfl_xor((int)acc.inf, m) != 0;
             acc = G1x::add(acc, o);
         }
-    } else if (role == 0 && lane == 0) {
-        atomicOr(reinterpret_cast<unsigned int*>(flags) + (p >> 2), 1u << (8 * (p & 3)));
     }
     if (lane == 0) G1x::store_xyzz(reinterpret_cast<fe*>(tmp) + ((size_t)role * batch + p) * 4, acc);
 }
@@ -340,7 +344,7 @@ void launch_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t
     hipLaunchKernelGGL(k_fin_scalarmul, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumA, sumB1, rs, batch, tmp, out, flags);
 }
 void launch_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const GlvSplit* glv, size_t batch, size_t nproofs, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
-    hipLaunchKernelGGL(k_fin_scalarmul_few, dim3((unsigned)nproofs, 2), dim3(64), 0, s, sumA, sumB1, glv, batch, tmp, out, flags);
+    hipLaunchKernelGGL(k_fin_scalarmul_few, dim3((unsigned)nproofs, 3), dim3(64), 0, s, sumA, sumB1, glv, batch, tmp, out, flags);      // roles: s * Ar, r * Bs1, Ar -> affine
 }
 void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s) {
     hipLaunchKernelGGL(k_fin_combine, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumB2, sumK, sumZ, tmp, batch, out, flags);
