@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void k_fin_scalarmul(const G1Xyzz* sumA, const 
 // doublings, nothing else on it), a lane keeps 2^(5q) A when the chain passes it (the k2 lanes apply phi: one product), multiplies it
 // by its chunk (5 doublings, <= 5 additions) and a butterfly adds the pieces up.  125 doublings + 16 additions on the critical
 // path instead of 254 + ~127 (and no field inversion: the chain starts from the XYZZ sum, a third wave turns Ar into the affine
-// form the proof carries): the longest serial chain of a single Prove, 2.3 -> 0.6 ms.
+// form the proof carries): the longest serial chain of a single Prove, 2.3 -> 0.68 ms.
 __global__ __launch_bounds__(64) void k_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const GlvSplit* glv, size_t batch,
                                                            G1Xyzz* tmp, uint8_t* out, uint8_t* flags) {
     using F = Fp29f;
