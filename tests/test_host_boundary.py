@@ -129,3 +129,9 @@ def test_solver_program_builder_and_key_parser_on_reference_files():
     assert rep["aes256.instr"] == "104106" and rep["aes256.inversions"] == "2384"
     assert rep["pk.A"] == "22001" and rep["pk.B"] == "12529" and rep["pk.Z"] == "32767" and rep["pk.K"] == "22128" and rep["pk.n"] == "32768"
     assert rep["truncated.r1cs"] == "rejected" and rep["truncated.pk"] == "rejected"
+    # the latency-path layout (build_few_program): every op once, every level only reads wires of earlier levels — also with the
+    # check-only constraints moved into the last level — and every wire gets solved
+    for c in ("chacha", "aes128", "aes256"):
+        assert rep[c + ".few_ops"] == rep[c + ".few_expected"] and rep[c + ".few_bad"] == "0" and rep[c + ".few_unsolved"] == "0", {k: v for k, v in rep.items() if k.startswith(c + ".few")}
+    assert rep["chacha.few_count_ops"] == "0" and rep["aes128.few_count_ops"] == "5"
+    assert int(rep["chacha.few_last_level"]) > 12000          # the 12 865 constraints that solve nothing run at the end
