@@ -167,7 +167,9 @@ def test_concurrent_prove_callers_share_device_batches(gsc_chacha, oracle, chach
         proof = base64.b64decode(out["proof"]["proofJson"]); ct = base64.b64decode(out["publicSignals"])
         assert ct == oracle.chacha20_xor(bytes(q["key"]), bytes(q["nonce"]), q["counter"], bytes(q["input"]))
         assert oracle.verify(vk, "chacha20", proof, _signals(ct, bytes(q["nonce"]), q["counter"], bytes(q["input"])))
-    assert elapsed < 0.6 * n * single, (elapsed, single)      # (a single Prove takes ~3 ms since the latency kernels; starting 96 Python threads is a good part of the rest)
+    # gathered calls must beat 96 sequential ones (a single Prove takes ~2.7 ms since the latency kernels; starting and joining 96 Python threads is a
+    # good part of what is left, so the bound is loose)
+    assert elapsed < 0.9 * n * single, (elapsed, single)
 
 
 def test_full_loop_through_both_drop_in_libraries_like_TestFullChaCha20(gsc_chacha):
