@@ -56,17 +56,91 @@ def pmc_traffic(kernel_tag, batch, engine_desc):
             d = json.load(open(path))
             c = d["config"]
             if c.get("kernel", "") == kernel_tag and c["batch"] == batch and ("window_z=%d " % c["window_z"]) in engine_desc:
-                return d["hbm_bytes_per_launch"]
+                return d["hbm_bytes_per_launch"], "replayed from %s (rocprofv3 PMC passes of this configuration; counters cannot be read inside the timed run)" % os.path.relpath(path, ROOT)
         except Exception:
             pass
-    return None
+    return None, None
+
+
+XOSHIRO_SEED = 0x9E3779B97F4A7C15
+
+
+def xoshiro_records(n, first_index):
+    """SURVEY.md §8(d): statement number `first_index + i` draws its 112-byte record {key[32], nonce[12], counter u32 LE, input[64]}
+    from a xoshiro256** stream of its own, seeded with 0x9E3779B97F4A7C15 + proofIndex (the 256-bit state is the first four outputs of
+    splitmix64 on that seed; the record is the stream's first 14 outputs, little-endian).  Anyone can rebuild statement k from k alone."""
+    import numpy as np
+    M = np.uint64
+    with np.errstate(over="ignore"):
+        x = (np.arange(n, dtype=np.uint64) + M(first_index & 0xFFFFFFFFFFFFFFFF)) + M(XOSHIRO_SEED)
+        st = []
+        for _ in range(4):                                   # splitmix64
+            x = x + M(0x9E3779B97F4A7C15)
+            z = x
+            z = (z ^ (z >> M(30))) * M(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> M(27))) * M(0x94D049BB133111EB)
+            st.append(z ^ (z >> M(31)))
+        s0, s1, s2, s3 = st
+        out = np.empty((n, 14), dtype="<u8")
+        for k in range(14):                                  # xoshiro256**
+            t = s1 * M(5)
+            out[:, k] = ((t << M(7)) | (t >> M(57))) * M(9)
+            t = s1 << M(17)
+            s2 = s2 ^ s0; s3 = s3 ^ s1; s1 = s1 ^ s2; s0 = s0 ^ s3
+            s2 = s2 ^ t
+            s3 = (s3 << M(45)) | (s3 >> M(19))
+    return out.tobytes()
 
 
 def synthetic_records(n, seed):
-    """n x 112 B {key[32], nonce[12], counter u32 LE, input[64]} — uniform bytes from a seeded generator."""
-    import numpy as np
-    rng = np.random.Generator(np.random.PCG64(seed))
-    return rng.integers(0, 256, size=(n, 112), dtype=np.uint8).tobytes()
+    """n x 112 B records of the statements seed * 2^32 + (0 .. n-1) (xoshiro_records)."""
+    return xoshiro_records(n, int(seed) << 32)
+
+
+def engine_env(workload, per_algo):
+    """The engine configuration a timed run uses (environment read by libprove at InitAlgorithm).  One place, so that the test of the
+    timed configuration (tests/test_gpu_00_bench_config.py) starts its prover with exactly these settings."""
+    env = {"GSC_MAX_BATCH": str(max(64, (per_algo + 63) // 64 * 64))}
+    if workload != "mixed":      # one algorithm alone on the device: widest Z digits that fit (ChaCha c = 16: 69 GB; AES c = 15: 137 GB); mixed keeps the
+        env["GSC_Z_TABLE_GB"] = "140"      # library defaults, under which all three algorithms are resident at once (3 x (48 + 16) GB)
+        env["GSC_W_TABLE_GB"] = "48"       # AES-V2 wide wires: c = 15 (42 GB) instead of 14
+    return env
+
+
+def sample_indices(n, want, edges=()):
+    """`want` statement indices spread evenly over a batch of n, always with 0, 63, 64, n - 1 and the given edges (chunk / replica
+    boundaries and their neighbours)."""
+    idx = {i for i in (0, 63, 64, n - 1) if 0 <= i < n}
+    for e in edges:
+        idx.update(i for i in (e - 1, e) if 0 <= i < n)
+    if want >= n:
+        return list(range(n))
+    k = 0
+    while len(idx) < want:
+        idx.add((k * n) // want); k += 1
+        if k > 4 * want:
+            break
+    return sorted(idx)
+
+
+def signals_of(name, rec, ct):
+    """publicSignals of one statement as the verifier wants them (libraries/verifier/impl/verifiers.go:59-62): ct | nonce | counter | pt,
+    the counter little-endian for ChaCha20 and big-endian for AES."""
+    ctr = rec[44:48] if name == "chacha20" else rec[44:48][::-1]
+    return ct + rec[32:44] + ctr + rec[48:112]
+
+
+def verify_items(g, items, threads=16):
+    """items: (cipher name, proof bytes, publicSignals bytes) -> list of verdicts from the product's libverify.so (CPU, like the
+    reference's verifier; ctypes releases the GIL, so the pairings run on `threads` host cores)."""
+    import base64
+    from concurrent.futures import ThreadPoolExecutor
+
+    def check(it):
+        cipher, proof, sig = it
+        return g.verify({"cipher": cipher, "proof": base64.b64encode(proof).decode(), "publicSignals": base64.b64encode(sig).decode()})
+    with ThreadPoolExecutor(threads) as pool:
+        return list(pool.map(check, items))
 
 
 def provable(rec, name):
@@ -79,10 +153,10 @@ def provable(rec, name):
     return bytes(b)
 
 
-def mixed_json(n, seed):
+def mixed_json(n, first_index):
     """JSON array for ProveBatch: statement i uses cipher i mod 3."""
     import base64
-    recs = provable(synthetic_records(n, seed), "aes")
+    recs = provable(xoshiro_records(n, first_index), "aes")
     names = ("chacha20", "aes128", "aes256")
     out = []
     for i in range(n):
@@ -199,6 +273,29 @@ class StubProver:
         return b"".join(self.h.sha256(recs[112 * i:112 * (i + 1)]).digest() * 5 + bytes(4) for i in range(self.B)), None
 
 
+WITNESS_BYTES_PER_PROOF = {"chacha20": 3_012_224, "aes128": 9_531_552, "aes256": 12_654_496}      # write W + a, b, c
+
+
+def roofline_of(n, rows, g):
+    """Roofline object of one algorithm's dominant kernel from the per-step records (kernel name, HIP-event ms, statements, columns,
+    bases per proof, stage ms): batch kernels -> the Z-table gather-accumulate priced on (64 + 32) B per base and proof; calls on the
+    latency path (a handful of statements) -> the resident witness kernel priced on §8(d)'s witness bytes.  Bytes are counted for the
+    STATEMENTS the launch proved, not for the 64-column padding."""
+    kname = rows[-1][0]; avg_ms = sum(r[1] for r in rows) / len(rows); stmts, cols, nb = rows[-1][2], rows[-1][3], rows[-1][4]
+    solver = kname.startswith("k_solver")
+    alg_bytes = stmts * (WITNESS_BYTES_PER_PROOF[n] if solver else nb * MSM_Z_BYTES_PER_BASE)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    msm_ms = sum(r[5]["msm"] for r in rows) / len(rows)
+    traffic, src = (None, None) if solver else pmc_traffic(n, cols, g.describe(ALGOS[n][0]))
+    return {"kernel": "%s (%s, %s)" % (kname, "resident witness solver of the latency path" if solver else "Z-table gather-accumulate", n), "bound": "hbm",
+            "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+            "traffic": traffic, "traffic_source": src, "launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
+            "proofs_per_launch": stmts, "columns_per_launch": cols,
+            "msm_stage": {"ms": round(msm_ms, 3), "bytes_per_proof": MSM_BYTES_PER_PROOF[n], "GB/s": round(stmts * MSM_BYTES_PER_PROOF[n] / (msm_ms * 1e-3) / 1e9, 2),
+                          "frac_of_hbm_peak": round(stmts * MSM_BYTES_PER_PROOF[n] / (msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+            "stage_ms_last_step": rows[-1][5]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,32 +304,47 @@ def main():
     ap.add_argument("--workload", choices=["chacha20", "aes128", "aes256", "mixed"], default="chacha20")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("GSC_BENCH_BATCH", "0")), help="proofs per GPU per step (default 8192 ChaCha, 1024 AES, 3072 mixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cores", type=int, default=0)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (default: all the process may run on)")
+    ap.add_argument("--verify", type=int, default=256, help="proofs of the LAST timed step checked with libverify.so after the clock stops (0 = none)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (rehearsal of the multi-GPU code path on a one-GPU box)")
+    ap.add_argument("--in-library", action="store_true", help="ONE process drives all --gpus devices through the library's own replicas (GSC_DEVICES=0..N-1): "
+                                                               "what a single FFI host (Go / node) would do; one call of N x batch statements per step")
+    ap.add_argument("--devices", default="", help="with --in-library: the device list itself (e.g. 0,0 rehearses two replicas on a one-GPU box)")
     ap.add_argument("--stub-prover", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if "RANK" not in os.environ and args.gpus > 1:
+    if args.in_library:
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        if len(devices) != args.gpus:
+            raise SystemExit("bench.py: --devices lists %d devices but --gpus is %d" % (len(devices), args.gpus))
+        if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("bench.py: --in-library is one process for all GPUs; do not start it under torch.distributed.run")
+    elif "RANK" not in os.environ and args.gpus > 1:
         return launch_ranks(args.gpus)
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    replicas = args.gpus if args.in_library else 1
+    rank = 0 if args.in_library else int(os.environ.get("RANK", "0"))
+    world = 1 if args.in_library else int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if args.in_library else int(os.environ.get("LOCAL_RANK", "0"))
+    if not args.in_library and world != args.gpus:
         raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: start one rank per GPU (or run `bench.py --gpus N` directly)" % (world, args.gpus))
     workload = args.workload
-    B = args.batch or {"chacha20": 8192, "aes128": 1024, "aes256": 1024, "mixed": 3072}[workload]
+    B = args.batch or {"chacha20": 8192, "aes128": 1024, "aes256": 1024, "mixed": 3072}[workload]      # per GPU
+    BT = B * replicas                                                                               # statements per call of this process
     # stdout carries exactly ONE JSON line (rank 0).  Native libraries print there too (libprove reports errors on stdout like the
     # reference's fmt.Println, RCCL prints a banner), so file descriptor 1 is pointed at stderr for the whole run and the line is
     # written to the saved descriptor at the end.
     sys.stdout.flush()
     json_fd = os.dup(1); os.dup2(2, 1)
-    os.environ["GSC_DEVICE"] = str(local_rank)
+    if args.in_library:
+        os.environ["GSC_DEVICES"] = ",".join(str(d) for d in devices)
+    else:
+        os.environ["GSC_DEVICE"] = str(local_rank)
     names = ["chacha20", "aes128", "aes256"] if workload == "mixed" else [workload]
     per_algo = B if workload != "mixed" else (B + 2) // 3
-    os.environ.setdefault("GSC_MAX_BATCH", str(max(64, (per_algo + 63) // 64 * 64)))
-    if workload != "mixed":      # one algorithm alone on the device: widest Z digits that fit (ChaCha c = 16: 69 GB; AES c = 15: 137 GB); mixed keeps the
-        os.environ.setdefault("GSC_Z_TABLE_GB", "140")      # library defaults, under which all three algorithms are resident at once (3 x (48 + 16) GB)
-        os.environ.setdefault("GSC_W_TABLE_GB", "48")       # AES-V2 wide wires: c = 15 (42 GB) instead of 14
+    for k, v in engine_env(workload, per_algo).items():
+        os.environ.setdefault(k, v)
     import torch
     import torch.distributed as dist
     stub = args.stub_prover
@@ -251,6 +363,7 @@ def main():
 
     import numpy as np
     g = None
+    vks = {}
     if not stub:
         import gsc_loader
         g = gsc_loader.load()
@@ -258,29 +371,36 @@ def main():
             algo = ALGOS[name][0]
             r1cs = golden("r1cs." + name)
             if name == "chacha20":
-                pk = golden("pk.chacha20")
+                pk, vks[name] = golden("pk.chacha20"), golden("vk.chacha20")
             else:
-                pk, _vk = g.setup(r1cs)                              # the product's own Groth16 Setup (GPU), CSPRNG toxic waste
+                pk, vks[name] = g.setup(r1cs)                        # the product's own Groth16 Setup (GPU), CSPRNG toxic waste
             if not g.init_algorithm(algo, pk, r1cs):
                 raise SystemExit("InitAlgorithm failed for " + name)
 
-    # statements of every step are made before the clock starts (112 B each: "inputs resident"); output buffers are reused
+    # statements of every step are made before the clock starts (112 B each: "inputs resident"); output buffers are reused.
+    # Statement number = rank * 2^44 + step id * 2^20 + position in the batch (xoshiro_records: reproducible by anyone).
     ids = [0x800000 + w for w in range(args.warmup)] + list(range(args.steps))
+    first_index = lambda i: (rank << 44) | ((i & 0xFFFFFF) << 20)
     if workload == "mixed":
-        inputs_of = {i: mixed_json(B, seed=(rank << 24) + (i & 0xFFFFFF)) for i in ids}
+        inputs_of = {i: mixed_json(BT, first_index(i)) for i in ids}
     else:
-        inputs_of = {i: provable(synthetic_records(B, seed=(rank << 24) + (i & 0xFFFFFF)), workload) for i in ids}
+        inputs_of = {i: provable(xoshiro_records(BT, first_index(i)), workload) for i in ids}
     import threading
     from concurrent.futures import ThreadPoolExecutor
     # Two callers keep the library busy, like concurrent Prove callers do (libraries/core_test.go:44-111): while one call's batch is on the
     # GPU, the other call does its host part (native cipher, CSPRNG draws, packing).  Device work of the two calls is serialised by the
     # library, so a step still means one batch through the whole path; each caller owns a set of output buffers.
     plen = 164 if workload == "chacha20" else 196
-    bufs = [g.raw_buffers(B) if g else None for _ in range(2)]
+    bufs = [g.raw_buffers(BT) if g else None for _ in range(2)]
     free = [threading.Event() for _ in range(2)]
     for e in free:
         e.set()
-    stubp = StubProver(B) if stub else None
+    stubp = StubProver(BT) if stub else None
+    last_json = {}
+
+    def kernel_stats(n):
+        kname, ms, stmts, cols, nb = g.last_dominant_kernel(ALGOS[n][0])
+        return (n, (kname, ms, stmts, cols, nb), g.last_stage_ms(ALGOS[n][0]))
 
     def prove(i, slot):
         free[slot].wait(); free[slot].clear()
@@ -288,33 +408,38 @@ def main():
             return stubp.step(inputs_of[i])
         if workload == "mixed":
             out = g.prove_batch_bytes(inputs_of[i])
-            if out.count(b'"proofJson"') != B:
-                raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, out.count(b'"proofJson"'), B))
-            return out, [(n, g.last_msm_z_kernel(ALGOS[n][0]), g.last_stage_ms(ALGOS[n][0])) for n in names]
+            if out.count(b'"proofJson"') != BT:
+                raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, out.count(b'"proofJson"'), BT))
+            last_json[i] = out
+            last_json.pop(i - 2, None)
+            return out, [kernel_stats(n) for n in names]
         pb, lb, cb = bufs[slot]
         algo = ALGOS[workload][0]
-        ok = g.prove_raw_into(algo, inputs_of[i], B, pb, lb, cb)
-        if ok != B:
-            raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, ok, B))
+        ok = g.prove_raw_into(algo, inputs_of[i], BT, pb, lb, cb)
+        if ok != BT:
+            raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, ok, BT))
         if not (np.frombuffer(lb, dtype=np.uint32) == plen).all():
             raise SystemExit("rank %d: incomplete proofs" % rank)
-        return pb, [(workload, g.last_msm_z_kernel(algo), g.last_stage_ms(algo))]
+        return pb, [kernel_stats(workload)]
 
     def run(step_ids, stats):
         with ThreadPoolExecutor(2) as pool:
             futs = [pool.submit(prove, i, k % 2) for k, i in enumerate(step_ids)]
+            last = len(futs) - 1
             for k, f in enumerate(futs):          # results are consumed in order on this thread (the only one that talks to RCCL)
                 payload, st = f.result()
                 raw = bytes(payload) if isinstance(payload, (bytes, bytearray)) else None
                 if raw is not None:               # JSON (mixed) or stub bytes: fixed-size frame for the gather
-                    frame = np.zeros(B * 416 if workload == "mixed" and not stub else len(raw), dtype=np.uint8)
+                    frame = np.zeros(BT * 416 if workload == "mixed" and not stub else len(raw), dtype=np.uint8)
                     frame[: len(raw)] = np.frombuffer(raw, dtype=np.uint8)[: frame.size]
                     local = torch.from_numpy(frame).to(dev)
                 else:
                     local = torch.frombuffer(payload, dtype=torch.uint8).to(dev)
-                free[k % 2].set()
+                if k != last or stats is None:    # the last timed step's buffers stay untouched: they are verified after the clock stops
+                    free[k % 2].set()
                 gather_proofs(dist, local, rank, world, use_dist)
-                stats.append(st)
+                if stats is not None:
+                    stats.append(st)
 
     def barrier():
         if use_dist:
@@ -322,7 +447,7 @@ def main():
         if not stub:
             torch.cuda.synchronize()
 
-    run(ids[:args.warmup], [])
+    run(ids[:args.warmup], None)
     barrier()
     t0 = time.time()
     stats = []
@@ -334,8 +459,45 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- parity gate for the timed configuration (libraries/core_test.go:171): a sample of the LAST timed step's proofs,
+    # spread over the batch (first / last wave, chunk and replica boundaries), goes through the product's verifier libverify.so under the
+    # verifying key that belongs to the proving key in use.  A rejection fails the run: no line is printed.
+    verified = 0
+    if not stub and args.verify > 0 and args.steps > 0:
+        import base64
+        for name in names:
+            if not g.init_verifier(ALGOS[name][0], vks[name]):
+                raise SystemExit("bench.py: InitVerifier failed for " + name)
+        last_id = ids[-1]
+        edges = [r * B for r in range(1, replicas)]
+        items = []
+        if workload == "mixed":
+            outs = json.loads(last_json[last_id]); reqs = json.loads(inputs_of[last_id])
+            for k in sample_indices(BT, args.verify, edges):
+                q, o = reqs[k], outs[k]
+                cname = {"chacha20": "chacha20", "aes-128-ctr": "aes128", "aes-256-ctr": "aes256"}[q["cipher"]]
+                rec = bytes(32) + base64.b64decode(q["nonce"]) + int(q["counter"]).to_bytes(4, "little") + base64.b64decode(q["input"])
+                items.append((q["cipher"], base64.b64decode(o["proof"]["proofJson"]), signals_of(cname, rec, base64.b64decode(o["publicSignals"]))))
+        else:
+            pb, lb, cb = bufs[(args.steps - 1) % 2]
+            recs = inputs_of[last_id]; cipher = ALGOS[workload][1]; proofs, cts = pb.raw, cb.raw
+            for k in sample_indices(BT, args.verify, edges):
+                items.append((cipher, proofs[196 * k:196 * k + plen], signals_of(workload, recs[112 * k:112 * (k + 1)], cts[64 * k:64 * k + 64])))
+        res = verify_items(g, items, threads=min(32, len(os.sched_getaffinity(0))))
+        if not all(res):
+            raise SystemExit("bench.py: rank %d: %d of %d sampled proofs of the last timed step were REJECTED by libverify.so" % (rank, res.count(False), len(res)))
+        # a proof must not verify for a neighbour's statement (the verifier is not a rubber stamp)
+        if len(items) > 1 and verify_items(g, [(items[0][0], items[0][1], items[1][2])], 1)[0] and items[0][2] != items[1][2]:
+            raise SystemExit("bench.py: libverify.so accepted a proof for another statement")
+        verified = len(res)
+        if use_dist:
+            tv = torch.tensor([verified], dtype=torch.int64, device=dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+            verified = int(tv.item())
+
     if rank == 0:
-        total = world * args.steps * B
+        ngpu = world * replicas
+        total = ngpu * args.steps * B
         value = total / elapsed
         metric = {"chacha20": "Groth16 proofs/sec (ChaCha20-V3 1-block)", "aes128": "Groth16 proofs/sec (AES-128-V2 64-byte input)",
                   "aes256": "Groth16 proofs/sec (AES-256-V2 64-byte input)", "mixed": "Groth16 proofs/sec (mixed ChaCha20-V3 / AES-128-V2 / AES-256-V2 batch)"}[workload]
@@ -343,47 +505,41 @@ def main():
                 "aes128": "AES-128-V2 (lookup-table circuit), 64-byte input, reference r1cs.aes128, proving key from the product's Setup (the reference ships none)",
                 "aes256": "AES-256-V2 (lookup-table circuit), 64-byte input, reference r1cs.aes256, proving key from the product's Setup (the reference ships none)",
                 "mixed": "mixed batch through ProveBatch (JSON in/out): statement i uses cipher i mod 3 of chacha20 / aes-128-ctr / aes-256-ctr, all three algorithms resident"}[workload]
+        par = ("in-library replicas: one process, GSC_DEVICES=%s, one call of %d statements per step split over the replicas" % (os.environ["GSC_DEVICES"], BT)) if args.in_library \
+            else "proofs sharded over %d GPU(s), one process per GPU, gather to rank 0" % world
         line = {
             "metric": metric, "value": round(value, 2), "unit": "proofs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fr/Fp, 254-bit modular integers)",
             "data": "synthetic",
-            "config": {"workload": "%s; 1xMI355X per rank: batch of %d independent proofs per GPU per step, CSPRNG (r,s)" % (desc, B),
-                       "batch_per_gpu": B, "parallelism": "proofs sharded over %d GPU(s), gather to rank 0" % world,
+            "config": {"workload": "%s; 1xMI355X per rank: batch of %d independent proofs per GPU per step, CSPRNG (r,s); statements from xoshiro256** seeded 0x9E3779B97F4A7C15 + index" % (desc, B),
+                       "batch_per_gpu": B, "parallelism": par,
                        "engine": {n: g.describe(ALGOS[n][0]) for n in names} if g else "stub"},
+            "verified": verified,
         }
         if not stub:
-            # dominant kernel = the Z-table MSM of the algorithm whose launch is longest; averaged over the timed steps
+            # dominant kernel of the algorithm whose launch is longest; averaged over the timed steps
             per = {}
             for st in stats:
-                for n, (ms, kb, nb), stage in st:
-                    per.setdefault(n, []).append((ms, kb, nb, stage))
-            roofs = {}
-            for n, rows in per.items():
-                avg_ms = sum(r[0] for r in rows) / len(rows); kb, nb = rows[-1][1], rows[-1][2]
-                alg_bytes = kb * nb * MSM_Z_BYTES_PER_BASE
-                achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-                msm_ms = sum(r[3]["msm"] for r in rows) / len(rows)
-                roofs[n] = {"kernel": "k_msm_win<Fp29f> (Z-table gather-accumulate, %s)" % n, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(n, kb, g.describe(ALGOS[n][0])),
-                            "launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg_bytes, "proofs_per_launch": kb,
-                            "msm_stage": {"ms": round(msm_ms, 3), "bytes_per_proof": MSM_BYTES_PER_PROOF[n], "GB/s": round(kb * MSM_BYTES_PER_PROOF[n] / (msm_ms * 1e-3) / 1e9, 2),
-                                          "frac_of_hbm_peak": round(kb * MSM_BYTES_PER_PROOF[n] / (msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
-                            "stage_ms_last_step": rows[-1][3]}
+                for n, (kname, ms, stmts, cols, nb), stage in st:
+                    per.setdefault(n, []).append((kname, ms, stmts, cols, nb, stage))
+            roofs = {n: roofline_of(n, rows, g) for n, rows in per.items()}
             dom = max(roofs, key=lambda n: roofs[n]["launch_ms"])
             line["roofline"] = dict(roofs[dom])
             bpp = BYTES_PER_PROOF[workload] if workload != "mixed" else sum(BYTES_PER_PROOF.values()) / 3.0
-            line["roofline"]["whole_path_frac"] = round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 6)
+            line["roofline"]["whole_path_frac"] = round(value / ngpu * bpp / 1e9 / HBM_PEAK_GBS, 6)
             line["msm_stage"] = line["roofline"].pop("msm_stage")
             line["stage_ms_last_step"] = line["roofline"].pop("stage_ms_last_step")
             if len(roofs) > 1:
                 line["roofline_per_algorithm"] = roofs
-            if world == 1 and not args.no_cpu_baseline:
-                cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
+            if ngpu == 1 and not args.no_cpu_baseline:
+                host_cores = os.cpu_count() or 1
+                cores = args.cpu_cores or len(os.sched_getaffinity(0))       # every core this process may run on ("all host cores")
                 try:
                     line["cpu_baseline"] = cpu_baseline(workload, cores)
                 except Exception as e:      # the baseline is reported, never required for the GPU number
                     line["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
+                line["cpu_baseline"]["host_cores"] = host_cores
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:

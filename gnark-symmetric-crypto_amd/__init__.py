@@ -20,7 +20,7 @@ CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
 ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
 
 EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw", "gsc_setup",
-           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_msm_z_kernel_ms", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_glv_split"]
+           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_dominant_kernel", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_glv_split"]
 
 
 class GoSlice(C.Structure):
@@ -66,8 +66,8 @@ def lib():
         L.gsc_describe.restype = C.c_size_t
         L.gsc_describe.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t]
         L.gsc_last_stage_ms.argtypes = [C.c_ubyte, C.POINTER(C.c_float)]
-        L.gsc_last_msm_z_kernel_ms.restype = C.c_float
-        L.gsc_last_msm_z_kernel_ms.argtypes = [C.c_ubyte, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.gsc_last_dominant_kernel.restype = C.c_int
+        L.gsc_last_dominant_kernel.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.gsc_debug_field_ops.restype = C.c_int
         L.gsc_debug_field_ops.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int]
         L.enforce_binding()
@@ -193,11 +193,27 @@ def last_stage_ms(algorithm_id: int):
     return dict(zip(("witness", "quotient", "msm", "assembly"), list(arr)))
 
 
+def last_dominant_kernel(algorithm_id: int):
+    """(kernel name, milliseconds, statements proved, padded columns, Z bases per proof) of the dominant kernel in the batch that
+    finished last: the Z-table MSM for batch calls, the resident witness solver for calls on the latency path."""
+    name = C.create_string_buffer(96)
+    ms, st, cols, nb = C.c_float(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    if lib().gsc_last_dominant_kernel(algorithm_id, name, 96, C.byref(ms), C.byref(st), C.byref(cols), C.byref(nb)) != 0:
+        return None
+    return name.value.decode(), float(ms.value), st.value, cols.value, nb.value
+
+
 def last_msm_z_kernel(algorithm_id: int):
-    """(milliseconds, proofs in the launch, bases per proof) of the dominant kernel in the last batch."""
-    b, nb = C.c_size_t(0), C.c_size_t(0)
-    ms = lib().gsc_last_msm_z_kernel_ms(algorithm_id, C.byref(b), C.byref(nb))
-    return float(ms), b.value, nb.value
+    """(milliseconds, columns in the launch, bases per proof) of the dominant kernel in the last batch (older tools)."""
+    k = last_dominant_kernel(algorithm_id)
+    return (k[1], k[3], k[4]) if k else None
+
+
+def served(algorithm_id: int):
+    """[(calls, statements)] per engine replica (GSC_DEVICES), parsed from gsc_describe."""
+    d = describe(algorithm_id)
+    tail = d.split("served(calls/statements)=")[1].split()[0]
+    return [tuple(int(x) for x in part.split("/")) for part in tail.split(",")]
 
 
 def debug_field_ops(field: int, op: int, a, b, chain=1):

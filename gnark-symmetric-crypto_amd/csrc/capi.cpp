@@ -6,6 +6,7 @@
 // {"proof":{"proofJson"},"publicSignals"} output, and "panic -> JSON" error reporting.
 #include "../../include/libprove.h"
 #include "engine.hpp"
+#include "dispatch.hpp"
 #include "glv.hpp"
 #include "host_ciphers.hpp"
 #include "json.hpp"
@@ -38,9 +39,10 @@ class Batcher {
   public:
     explicit Batcher(Algorithm* a) : algo_(a) {
         const char* e = getenv("GSC_LINGER_US"); linger_us_ = e && *e ? atoi(e) : 300;
-        // one worker per lane of the engine: while one device batch is in its latency-bound stages, the next one is already being
-        // gathered and proved on the other lane (AES-V2 has two lanes by default, ChaCha20-V3 one)
-        const size_t nw = a->lanes() ? a->lanes() : 1;
+        // one worker per (device, lane) of the engine: while one device batch is in its latency-bound stages, the next one is already
+        // being gathered and proved on another lane (AES-V2 has two lanes by default, ChaCha20-V3 one) or on another GPU
+        // (GSC_DEVICES: prove_batch hands every small batch to the least-loaded replica)
+        const size_t nw = (a->lanes() ? a->lanes() : 1) * (a->devices() ? a->devices() : 1);
         for (size_t i = 0; i < nw; i++) workers_.emplace_back([this] { run(); });
     }
     ~Batcher() { { std::lock_guard<std::mutex> l(mu_); stop_ = true; } cv_.notify_all(); for (auto& w : workers_) if (w.joinable()) w.join(); }
@@ -57,13 +59,18 @@ class Batcher {
             std::vector<Item*> take;
             {
                 std::unique_lock<std::mutex> l(mu_);
+                idle_++;
                 cv_.wait(l, [&] { return stop_ || !q_.empty(); });
                 if (stop_ && q_.empty()) return;
-                // linger only when it can pay: a burst is arriving (more than one caller queued) or a batch of this algorithm is on the device
+                // linger only when it can pay: a burst is arriving (more than one caller queued) or every device has a batch of this algorithm on it
                 // anyway — a lone caller on an idle device goes at once (a single Prove takes 2.7 ms: 0.3 ms of waiting would be 11 % of it)
-                if (linger_us_ > 0 && (q_.size() > 1 || in_flight_ > 0) && q_.size() < algo_->max_batch())
+                if (linger_us_ > 0 && (q_.size() > 1 || in_flight_ >= (int)algo_->devices()) && q_.size() < algo_->max_batch())
                     cv_.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return stop_ || q_.size() >= algo_->max_batch(); });
-                while (!q_.empty() && take.size() < algo_->max_batch()) { take.push_back(q_.front()); q_.pop_front(); }
+                // the queue is shared out over the workers that have nothing on a device (this one included): a burst of callers
+                // spreads over every replica and lane; a worker that is alone takes everything (dispatch.hpp)
+                const size_t want = batcher_take(q_.size(), (size_t)idle_, algo_->max_batch());
+                idle_--;
+                while (!q_.empty() && take.size() < want) { take.push_back(q_.front()); q_.pop_front(); }
                 if (!take.empty()) in_flight_++;
             }
             if (take.empty()) continue;                    // another worker took them while this one lingered
@@ -79,7 +86,7 @@ class Batcher {
             done_cv_.notify_all();
         }
     }
-    Algorithm* algo_; int linger_us_ = 300; int in_flight_ = 0; bool stop_ = false;
+    Algorithm* algo_; int linger_us_ = 300; int in_flight_ = 0, idle_ = 0; bool stop_ = false;
     std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Item*> q_; std::vector<std::thread> workers_;
 };
 
@@ -92,7 +99,7 @@ DebugVectors g_debug;
 // zero-knowledge for every caller of the process.  They refuse to work unless the process was started with
 // GSC_ENABLE_TEST_HOOKS=1; the variable is read ONCE, when the library is loaded, so code running inside the host cannot
 // switch them on later.
-const bool g_test_hooks = [] { const char* e = getenv("GSC_ENABLE_TEST_HOOKS"); return e && e[0] == '1' && e[1] == 0; }();
+const bool g_test_hooks = test_hooks_enabled();
 bool hooks_refused(const char* what) {
     if (g_test_hooks) return false;
     printf("%s refused: test hooks are disabled (start the process with GSC_ENABLE_TEST_HOOKS=1)\n", what);
@@ -350,7 +357,7 @@ long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t
     Algorithm* a = lookup(cipher);
     if (!a) return -1;
     try {
-        const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
+        static const bool trace = getenv("GSC_TRACE_HOST") != nullptr;      // read once
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<ProofRequest> reqs(n); std::vector<ProofResult> res(n);
         for (size_t i = 0; i < n; i++) {
@@ -444,15 +451,23 @@ size_t gsc_describe(GoUint8 algorithmID, char* out, size_t cap) {
     std::string s = a ? a->describe() : std::string("not initialised");
     size_t n = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(out, s.data(), n); out[n] = 0; return n;
 }
-float gsc_last_msm_z_kernel_ms(GoUint8 algorithmID, size_t* batch, size_t* nbases) {
-    if (algorithmID > 2) return -1.f;
-    Algorithm* a = lookup(algorithmID); if (!a) return -1.f;
-    return a->last_msm_z_kernel_ms(batch, nbases);
+int gsc_last_dominant_kernel(GoUint8 algorithmID, char* name, size_t cap, float* ms, size_t* statements, size_t* columns, size_t* nbases) {
+    if (algorithmID > 2) return -1;
+    Algorithm* a = lookup(algorithmID); if (!a) return -1;
+    const KernelStat st = a->last_kernel_stat();
+    if (name && cap) { const size_t n = strlen(st.name) < cap - 1 ? strlen(st.name) : cap - 1; memcpy(name, st.name, n); name[n] = 0; }
+    if (ms) *ms = st.ms;
+    if (statements) *statements = st.statements;
+    if (columns) *columns = st.columns;
+    if (nbases) *nbases = st.nbases;
+    return 0;
 }
 int gsc_last_stage_ms(GoUint8 algorithmID, float out[4]) {
     if (algorithmID > 2) return -1;
     Algorithm* a = lookup(algorithmID); if (!a) return -1;
-    a->last_stage_ms(out); return 0;
+    const KernelStat st = a->last_kernel_stat();
+    for (int i = 0; i < 4; i++) out[i] = st.stage_ms[i];
+    return 0;
 }
 
 }  // extern "C"

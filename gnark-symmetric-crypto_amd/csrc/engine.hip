@@ -1,6 +1,7 @@
 // GPU prover engine: InitAlgorithm-time upload / table build and the per-batch device pipeline.
 // See engine.hpp for the reference interface this mirrors.
 #include "engine.hpp"
+#include "dispatch.hpp"
 #include "formats.hpp"
 #include "kernels.hpp"
 #include "host_ciphers.hpp"
@@ -67,6 +68,12 @@ struct MsmSet {                     // one fixed-base MSM of the proving key (ke
 
 }  // namespace
 
+bool test_hooks_enabled() {
+    static const bool on = [] { const char* e = getenv("GSC_ENABLE_TEST_HOOKS"); return e && e[0] == '1' && e[1] == 0; }();
+    return on;
+}
+namespace { const bool g_hooks_read_at_load = test_hooks_enabled(); }      // forces the evaluation when the library is loaded
+
 EngineConfig config_from_env() {
     EngineConfig c;
     c.device = env_int("GSC_DEVICE", 0);
@@ -81,19 +88,17 @@ EngineConfig config_from_env() {
     c.window_w = env_int("GSC_WINDOW_W", 0);
     c.z_table_gb = env_int("GSC_Z_TABLE_GB", 48);
     c.w_table_gb = env_int("GSC_W_TABLE_GB", 16);
-    c.msm_placement = env_int("GSC_MSM_PLACEMENT", 0);
     c.row_margin_bits = env_int("GSC_ROW_MARGIN_BITS", 1);
     c.few_path = env_int("GSC_FEW_PATH", 1);
     c.few_solver = env_int("GSC_FEW_SOLVER", 1);
     c.few_max = env_int("GSC_FEW_MAX", 0);
     if (c.few_max < 0 || c.few_max > (int)MSM_FEW_PROOFS) throw std::runtime_error("GSC_FEW_MAX must be in [0, 32]");
     c.few_workgroups = env_int("GSC_FEW_WGS", 0);
-    c.few_coherent = env_int("GSC_FEW_COHERENT", 1);
     c.few_z_gb = env_int("GSC_FEW_Z_GB", 12);
     c.few_wide = env_int("GSC_FEW_WIDE", 1);
     if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");
-    c.win_slice = (size_t)env_int("GSC_WIN_SLICE", 256);
-    if (c.win_slice < 8 || c.win_slice > 4096) throw std::runtime_error("GSC_WIN_SLICE must be in [8, 4096]");
+    c.trace_host = getenv("GSC_TRACE_HOST") != nullptr;
+    if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; }
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
     if ((c.window_z && (c.window_z < 4 || c.window_z > 16)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [4,16]");
@@ -122,6 +127,11 @@ class AlgorithmImpl {
         return got;
     }
     std::atomic<int> calls_in_flight{0};
+    int cu_count = 256;                 // compute units of the device: the resident witness kernel needs one per workgroup
+    // After a resident launch gave up (CUs held by someone else), the next few_skip calls of this replica go level by level at once
+    // instead of spinning through the same timeouts; the penalty doubles up to 4096 calls and is forgotten after a success.
+    std::atomic<uint32_t> few_skip{0}; std::atomic<uint32_t> few_penalty{16};
+    std::mutex stat_mu; KernelStat last_stat;      // timing of the chunk that finished last on this replica
     void release_lane(size_t i) { { std::lock_guard<std::mutex> l(pool_mu); lane_busy[i] = 0; } pool_cv.notify_all(); }
     hipStream_t stream = nullptr;   // init-time work; proving runs on the lanes' streams
     size_t table_bytes = 0;
@@ -174,7 +184,8 @@ class AlgorithmImpl {
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the GPU prover has no CPU fallback");
         HIP_CHECK(hipSetDevice(cfg.device));
         HIP_CHECK(hipStreamCreate(&stream));
-        const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
+        { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg.device) == hipSuccess && cus > 0) cu_count = cus; }
+        const bool trace = cfg.trace_host;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         const auto t0 = now();
@@ -495,7 +506,7 @@ class AlgorithmImpl {
         }
         auto dec1 = [this](const std::vector<uint8_t>& raw, G1Aff* out) { return decompress_g1(raw, out); };
         auto dec2 = [this](const std::vector<uint8_t>& raw, G2Aff* out) { return decompress_g2(raw, out); };
-        const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
+        const bool trace = cfg.trace_host;
         auto timed = [&](const char* what, auto&& fn) {
             const auto a0 = std::chrono::steady_clock::now(); const size_t b0 = table_bytes; fn();
             if (trace) fprintf(stderr, "  tables %-8s %7.0f ms %8.2f GiB\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count(), (table_bytes - b0) / 1073741824.0);
@@ -547,7 +558,7 @@ class AlgorithmImpl {
                 if (o2 * 64 > dg) dg = o2 * 64;
                 part(0, ((m.nflat + 7) / 8 + 63) / 64 + (o2 + 63) / 64, 64);
             }
-            if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, cfg.win_slice, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
+            if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, WIN_SLICE, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
         };
         MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew};
         for (size_t b = 64; b <= B; b += 64) {
@@ -586,6 +597,7 @@ class AlgorithmImpl {
         n = (nbases + per - 1) / per;
         return n ? n : 1;
     }
+    static constexpr size_t WIN_SLICE = 256;      // bases per slice of the windowed kernel at full batches (measured 64 .. 512: kernel time within 1 %)
     bool few_solver_wanted(size_t n, size_t B) const { return n <= (size_t)cfg.few_max && B == 64 && cfg.few_solver; }
     struct MsmCtx { hipStream_t stream; uint4* digits; uint8_t* gok; };
     template <class XyzzT, class LR>
@@ -662,13 +674,12 @@ class AlgorithmImpl {
             // a single Prove call (lanes = bases): slices of 512 bases — 8 gathers + 6 butterfly additions per wave, and at most 64 partial
             // sums per column, which one reduction launch folds
             const bool few = fewm;
-            size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, cfg.win_slice, B, per);
+            size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, WIN_SLICE, B, per);
             if (few && nslices > (set.nwide + 511) / 512) { per = 512; nslices = (set.nwide + 511) / 512; }
             const size_t Bw = B * (size_t)set.nwin;
             MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ctx.digits};
             launch_msm_recode(ra, ctx.stream);
-            MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa, cfg.msm_placement, 0};
-            if (const char* e = getenv("GSC_MSM_EXP")) { if (getenv("GSC_ENABLE_TEST_HOOKS") && (atoi(e) & 1)) a.exp_same_entry = 1; if (atoi(e) & 2) a.placement = 1; if (atoi(e) & 4) a.placement = 0; }
+            MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa};
             if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
             if (few) launch_win_few(a, n_real, ctx.stream);
             else launch_win(a, ctx.stream);
@@ -708,7 +719,7 @@ class AlgorithmImpl {
     void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver = true) {
         const size_t B = (n + 63) / 64 * 64;
         ln.n_real = n;
-        const bool trace = getenv("GSC_TRACE_HOST") != nullptr;
+        const bool trace = cfg.trace_host;
         const auto tc0 = std::chrono::steady_clock::now();
         std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs, n, B, h_in, h_rs);
         ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
@@ -737,17 +748,23 @@ class AlgorithmImpl {
         SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p,
                       has_commitment ? ln.d_mask.p : nullptr, has_commitment ? ln.d_commit.p : nullptr, has_div, 0u, nullptr};
         DevBuf<unsigned long long> d_trace;
-        const bool strace = getenv("GSC_SOLVER_TRACE") && getenv("GSC_ENABLE_TEST_HOOKS");
+        const bool strace = cfg.solver_trace;
         if (strace) {
             std::vector<unsigned long long> init(16 * ((size_t)n_levels + 1), 0ull);
             if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[16 * l] = ~0ull;
             d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
         }
-        const bool few_solver = few_solver_wanted(n, B) && allow_few_solver;
+        bool few_solver = few_solver_wanted(n, B) && allow_few_solver;
+        if (few_solver) {      // a recent give-up on this replica: skip the resident kernel for a while (see few_skip)
+            uint32_t k = few_skip.load();
+            while (k && !few_skip.compare_exchange_weak(k, k - 1)) {}
+            if (k) few_solver = false;
+        }
+        const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
         if (few_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
         SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
-                         ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, 1u << 21, 0u, (uint32_t)cfg.few_coherent, n_levels, nullptr};
-        if (getenv("GSC_FEW_TEST_ABORT") && getenv("GSC_ENABLE_TEST_HOOKS")) { fa.poll_limit = 256; fa.test_missing = 1; }      // test: the barrier never fills
+                         ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, 1u << 21, 0u, n_levels, nullptr};
+        if (cfg.few_test_abort) { fa.poll_limit = 256; fa.test_missing = 1; }      // test: the barrier never fills
         auto run_levels = [&](uint32_t from, uint32_t to) {
             for (uint32_t l = from; l < to; l++) {
                 sa.first_level = l; sa.n_long = level_long[l];
@@ -762,7 +779,11 @@ class AlgorithmImpl {
                         FewSolverChain& chain = few_solver_chain(cfg.device);
                         std::lock_guard<std::mutex> lk(chain.m);
                         if (chain.last && chain.last != ln.ev_few) HIP_CHECK(hipStreamWaitEvent(ln.stream, chain.last, 0));
-                        launch_solver_few(fa, has_div, cfg.few_workgroups ? (uint32_t)cfg.few_workgroups : (n <= 2 ? 128u : 256u), ln.stream);      // measured: 128 workgroups best for 1-2 statements, 256 (one per CU) beyond
+                        // measured: 128 workgroups best for 1-2 statements, 256 (one per CU) beyond; never more than the device has CUs
+                        // (every workgroup must be resident: one per CU by construction) — the kernel works with any grid
+                        uint32_t wgs = cfg.few_workgroups ? (uint32_t)cfg.few_workgroups : (n <= 2 ? 128u : 256u);
+                        if (wgs > (uint32_t)cu_count) wgs = (uint32_t)cu_count;
+                        launch_solver_few(fa, has_div, wgs, ln.stream);
                         HIP_CHECK(hipEventRecord(ln.ev_few, ln.stream));
                         chain.last = ln.ev_few;
                     }
@@ -771,6 +792,7 @@ class AlgorithmImpl {
             }
         };
         std::vector<uint8_t> h_cpts;
+        if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));      // dominant kernel of a latency-path call: the witness solver
         if (has_commitment) {
             // Groth16 commitment (gnark "BSB22"): solve up to the commitment hint, D = sum w_j * Basis_j over the
             // committed wires (same MSM kernels as everything else), challenge = hash_to_field(D uncompressed) on the device, resume:
@@ -783,6 +805,7 @@ class AlgorithmImpl {
             h_cpts.resize(128 * B);
             run_levels(commit_level, n_levels);
         } else run_levels(0, n_levels);
+        if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
         if (strace) {
             HIP_CHECK(hipStreamSynchronize(ln.stream));
             std::vector<unsigned long long> t(16 * ((size_t)n_levels + 1));
@@ -843,7 +866,7 @@ class AlgorithmImpl {
         }
         HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
         run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
-        run_msm_g1(ln, ln.n_real <= (size_t)cfg.few_max && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, true);
+        run_msm_g1(ln, ln.n_real <= (size_t)cfg.few_max && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
         if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
         flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
         if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
@@ -868,10 +891,19 @@ class AlgorithmImpl {
         if (h_fsync[1]) {      // the resident solver gave up (its workgroups never became resident together: another process's kernel on this device)
             static std::atomic<bool> warned{false};
             if (!warned.exchange(true)) fprintf(stderr, "libprove: the resident witness kernel could not hold the device (shared with another process?); solving level by level\n");
+            const uint32_t pen = few_penalty.load();
+            few_skip.store(pen); few_penalty.store(pen < 4096 ? pen * 2 : 4096);
             return prove_chunk(ln, reqs, n, results, dbg, false);
         }
+        if (few_solver) few_penalty.store(16);
         for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
         (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
+        {
+            std::lock_guard<std::mutex> lk(stat_mu);
+            last_stat.name = latency_call ? (few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
+            last_stat.ms = ln.msm_z_kernel_ms; last_stat.statements = n; last_stat.columns = B; last_stat.nbases = mZ.nwide;
+            for (int k = 0; k < 4; k++) last_stat.stage_ms[k] = ln.stage_ms[k];
+        }
         for (size_t i = 0; i < n; i++)
             serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts.data() + 64 * i : nullptr, has_commitment ? h_cpts.data() + 64 * B + 64 * i : nullptr, results[i]);
         if (trace) {
@@ -941,14 +973,18 @@ Algorithm::Algorithm(Cipher cipher, const uint8_t* pk, size_t pk_len, const uint
     make(0);
     for (auto& t : th) t.join();
     if (err) { impls_.clear(); std::rethrow_exception(err); }
+    picker_.reset(new ReplicaPicker(impls_.size()));
 }
 Algorithm::~Algorithm() = default;
 Cipher Algorithm::cipher() const { return impls_[0]->cipher; }
 size_t Algorithm::max_batch() const { size_t c = 0; for (auto& i : impls_) c += i->cap; return c; }
 size_t Algorithm::devices() const { return impls_.size(); }
 size_t Algorithm::lanes() const { return impls_[0]->lanes.size(); }
-void Algorithm::last_stage_ms(float out[4]) const { for (int i = 0; i < 4; i++) out[i] = impls_[0]->lanes[0]->stage_ms[i]; }
-float Algorithm::last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const { if (batch) *batch = impls_[0]->lanes[0]->last_batch; if (nbases) *nbases = impls_[0]->mZ.nwide; return impls_[0]->lanes[0]->msm_z_kernel_ms; }
+KernelStat Algorithm::last_kernel_stat() const {
+    AlgorithmImpl* a = impls_[last_replica_.load() < impls_.size() ? last_replica_.load() : 0].get();
+    std::lock_guard<std::mutex> lk(a->stat_mu);
+    return a->last_stat;
+}
 std::string Algorithm::describe() const {
     const AlgorithmImpl* impl_ = impls_[0].get();
     char buf[640];
@@ -956,7 +992,12 @@ std::string Algorithm::describe() const {
              impl_->n_wires, impl_->n_constraints, impl_->L, max_batch(), impl_->lanes.size(), impls_.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
              impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases, impl_->mA.nbit, impl_->mB1.nbit, impl_->mK.nbit,
              impl_->mA.nwide, impl_->mA.nexpanded, impl_->mB1.nwide, impl_->mB1.nexpanded, impl_->mK.nwide, impl_->mK.nexpanded);
-    return buf;
+    // per replica: calls and statements it has served (ReplicaPicker): shows that small calls reach every device
+    std::string out = buf;
+    out += " served(calls/statements)=";
+    const auto sv = picker_->served();
+    for (size_t i = 0; i < sv.size(); i++) out += (i ? "," : "") + std::to_string(sv[i].calls) + "/" + std::to_string(sv[i].statements);
+    return out;
 }
 size_t Algorithm::domain_size() const { return impls_[0]->domain_n; }
 void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out) {
@@ -1013,7 +1054,13 @@ static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t 
 void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
     if (!n) return;
     const size_t nd = impls_.size();
-    if (nd == 1 || n <= 64) return prove_on_replica(*impls_[0], reqs, n, results, debug_first);
+    struct Held { ReplicaPicker& p; size_t i, n; std::atomic<size_t>& last; ~Held() { p.release(i, n); last.store(i); } };
+    if (nd == 1 || n <= 64) {
+        // A call of up to one 64-column batch is not split: it goes, whole, to the least-loaded replica (ReplicaPicker) — concurrent
+        // single-proof callers and the micro-batcher's small batches therefore use every GPU of the node, not only the first one.
+        Held h{*picker_, picker_->acquire(n), n, last_replica_};
+        return prove_on_replica(*impls_[h.i], reqs, n, results, debug_first);
+    }
     // Proofs are independent: contiguous shares (multiples of 64) go to the replicas, one host thread per device; nothing is
     // exchanged between devices (the "gather" is the results array the threads fill).
     size_t share = ((n + nd - 1) / nd + 63) / 64 * 64;
@@ -1021,7 +1068,10 @@ void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* res
     auto work = [&](size_t d) {
         const size_t off = d * share;
         if (off >= n) return;
-        try { prove_on_replica(*impls_[d], reqs + off, n - off < share ? n - off : share, results + off, d == 0 ? debug_first : nullptr); }
+        const size_t take = n - off < share ? n - off : share;
+        picker_->acquire_on(d, take);
+        Held h{*picker_, d, take, last_replica_};
+        try { prove_on_replica(*impls_[d], reqs + off, take, results + off, d == 0 ? debug_first : nullptr); }
         catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
     };
     for (size_t d = 1; d < nd; d++) th.emplace_back(work, d);

@@ -5,6 +5,7 @@
 // to HBM and builds the fixed-base tables; "Prove" runs the device pipeline for a batch of independent proofs.
 #pragma once
 #include <cstdint>
+#include <atomic>
 #include <cstddef>
 #include <memory>
 #include <string>
@@ -38,17 +39,28 @@ struct EngineConfig {
     int z_table_gb = 48, w_table_gb = 16;   // per-algorithm HBM budgets used when the widths are not given (all three algorithms of the reference fit one 288 GB device)
     int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no prediction-based layout; 1 bit groups / row lengths from a calibration witness; 2 every wire predicted a bit (test: exercises the fallbacks)
     int row_margin_bits = 1;     // GSC_ROW_MARGIN_BITS: a wire seen with k-bit values gets a row of 2^(k + margin) multiples (capped at 2^(c-1))
-    size_t win_slice = 256;      // GSC_WIN_SLICE: bases per slice of the windowed MSM kernel at full batches (measured 64 .. 512: kernel time within 1 %)
     int few_path = 1;            // GSC_FEW_PATH: calls with at most few_max statements use the latency kernels for the MSMs, the quotient and the assembly; 0 = always the batch kernels
     int few_max = 0;             // GSC_FEW_MAX: the largest call the latency kernels take (<= MSM_FEW_PROOFS = 32); 0 = 32 for ChaCha20 (4.6 ms for 1 statement, 7.8 ms for 16, 11.3 ms for 32; the batch kernels need 12.3 ms for anything up to 64), 20 for AES (8.2 ms for 1, +1.6 ms each: 38.4 ms for 20; batch kernels 43.7 ms)
     int few_solver = 1;          // GSC_FEW_SOLVER: such calls also solve the witness with the resident lanes-are-terms kernel (k_solver_few); 0 = one launch per level
     int few_workgroups = 0;      // GSC_FEW_WGS: its grid (workgroups of 8 waves, one per CU, so all are resident); 0 = 128 for 1-2 statements, 256 beyond
     int few_z_gb = 12;           // GSC_FEW_Z_GB: HBM budget of the latency-path layout of the quotient bases (rows per (base, window) of 8-, 6- or 4-bit digits: 8.6 GB ChaCha20 at 8, 11.5 GB AES at 6); 0 = none, such calls run the Horner pass
     int few_wide = 1;            // GSC_FEW_WIDE: the wide wires of the wire sets (AES: ~6 k per set) also get (base, window) rows for the latency path (~7.5 GB per AES algorithm); 0 = such calls run the windowed kernel + Horner for them
-    int few_coherent = 1;        // GSC_FEW_COHERENT: 1 wire values cross workgroups through device-scope accesses; 0 plain accesses + L2 write-back / invalidate at every barrier
-    int msm_placement = 0;       // GSC_MSM_PLACEMENT: workgroup placement of the MSM kernel (kernels.hpp MsmWinArgs::placement)
+    bool trace_host = false;     // GSC_TRACE_HOST: host-side timing lines on stderr (InitAlgorithm breakdown, per-chunk enqueue / wait / serialise)
+    // diagnostics that change what the device does: honoured only when the test hooks were enabled at load time (test_hooks_enabled())
+    bool solver_trace = false;   // GSC_SOLVER_TRACE: per-level clock stamps of the witness kernels
+    bool few_test_abort = false; // GSC_FEW_TEST_ABORT: the resident witness kernel's barrier never fills (exercises the give-up path)
 };
+// Every knob is read HERE, once per InitAlgorithm / gsc_setup call — never on the proving path (getenv there would race with a
+// host that calls setenv from another thread, and would let code inside the host flip diagnostics mid-flight).
 EngineConfig config_from_env();
+// GSC_ENABLE_TEST_HOOKS == "1" in the environment when libprove.so was LOADED (evaluated once, by a load-time initialiser).
+bool test_hooks_enabled();
+
+// The dominant kernel of a call, as the engine timed it with HIP events on the kernel's own stream (bench.py's roofline object).
+// Batch calls: the Z-table gather-accumulate k_msm_win<Fp29f>.  Calls on the latency path (a handful of statements): the resident
+// witness kernel k_solver_few, which is half of such a call.  statements = what the call proved; columns = the 64-padded batch the
+// kernels ran on; nbases = fixed bases per proof of the Z set.
+struct KernelStat { const char* name = ""; float ms = 0; size_t statements = 0, columns = 0, nbases = 0; float stage_ms[4] = {0, 0, 0, 0}; };
 
 // what: 0 W (Montgomery), 1 A, 2 B, 3 C (Montgomery; valid until computeH overwrites them: only with keep_abc), 4 h (canonical, bit-reversed order)
 struct DebugVectors { std::vector<uint8_t> W, A, B, C, H; size_t n_wires = 0, n_constraints = 0, n = 0; };
@@ -66,11 +78,8 @@ class Algorithm {
     size_t devices() const;
     size_t lanes() const;          // lanes of one replica: how many device batches can be in flight per device
     std::string describe() const;    // sizes, table memory — for logs / DESIGN numbers
-    // raw timing of the last prove_batch, milliseconds per stage (solve, ntt, msm, finalize), device events
-    void last_stage_ms(float out[4]) const;
-    // HIP-event duration of the dominant kernel (k_msm<Fp> over the Z tables) in the last batch, the padded batch it ran on
-    // and the number of bases it covered
-    float last_msm_z_kernel_ms(size_t* batch, size_t* nbases) const;
+    // timing of the chunk that finished last (any replica, any lane): stage milliseconds (solve, ntt, msm, finalize) and the dominant kernel
+    KernelStat last_kernel_stat() const;
     // TEST HOOK: the quotient kernels alone on caller-supplied vectors.  abc_be: three matrices [m][64] of canonical big-endian
     // 32-byte values (a, then b, then c; 64 independent columns), m <= number of constraints.  h_out: [domain][64] 32-byte
     // little-endian canonical values, row k = coefficient bitrev(k).
@@ -78,6 +87,8 @@ class Algorithm {
     size_t domain_size() const;
   private:
     std::vector<std::unique_ptr<AlgorithmImpl>> impls_;      // one per device
+    std::unique_ptr<class ReplicaPicker> picker_;            // dispatch.hpp: least-loaded replica for calls that are not split
+    mutable std::atomic<size_t> last_replica_{0};            // the replica whose chunk finished last (last_kernel_stat)
 };
 
 // TEST HOOK: runs element-wise operations of the device's radix-2^29 field implementation (see kernels.hpp launch_field_ops).

@@ -11,9 +11,21 @@ using u64 = uint64_t;
 using u128 = unsigned __int128;
 
 struct U256 { u64 w[4]; };
-inline bool geq(const U256& a, const U256& b) { for (int i = 3; i >= 0; i--) { if (a.w[i] != b.w[i]) return a.w[i] > b.w[i]; } return true; }
-inline u64 sub_into(U256& a, const U256& b) { u64 br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a.w[i] - b.w[i] - br; a.w[i] = (u64)d; br = (u64)(d >> 64) & 1; } return br; }
-inline u64 add_into(U256& a, const U256& b) { u64 c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)a.w[i] + b.w[i] + c; a.w[i] = (u64)s; c = (u64)(s >> 64); } return c; }
+constexpr bool geq(const U256& a, const U256& b) { for (int i = 3; i >= 0; i--) { if (a.w[i] != b.w[i]) return a.w[i] > b.w[i]; } return true; }
+constexpr u64 sub_into(U256& a, const U256& b) { u64 br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a.w[i] - b.w[i] - br; a.w[i] = (u64)d; br = (u64)(d >> 64) & 1; } return br; }
+constexpr u64 add_into(U256& a, const U256& b) { u64 c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)a.w[i] + b.w[i] + c; a.w[i] = (u64)s; c = (u64)(s >> 64); } return c; }
+// 2^bits mod m by repeated doubling (compile time: the Montgomery constants below are constexpr, so no thread ever sees them half-built)
+constexpr U256 pow2_mod(int bits, const U256& m) {
+    U256 t{{1, 0, 0, 0}};
+    for (int i = 0; i < bits; i++) {
+        const u64 top = t.w[3] >> 63;
+        for (int k = 3; k > 0; k--) t.w[k] = (t.w[k] << 1) | (t.w[k - 1] >> 63);
+        t.w[0] <<= 1;
+        if (top || geq(t, m)) sub_into(t, m);
+    }
+    return t;
+}
+constexpr u64 neg_inv64(u64 m0) { u64 inv = 1; for (int i = 0; i < 6; i++) inv *= 2 - m0 * inv; return 0 - inv; }
 
 // prime field with Montgomery representation; Tag selects the modulus
 template <int Tag>
@@ -21,21 +33,9 @@ struct Fe {
     U256 v;   // Montgomery form
     static constexpr U256 MOD = Tag == 0 ? U256{{0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull}}     // p
                                          : U256{{0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull}};    // r
-    static inline U256 R1{}, R2{}; static inline u64 NINV = 0; static inline bool ready = false;
-    static void init() {
-        if (ready) return;
-        u64 inv = 1; for (int i = 0; i < 6; i++) inv *= 2 - MOD.w[0] * inv;
-        NINV = 0 - inv;
-        U256 t{{1, 0, 0, 0}};
-        for (int i = 0; i < 512; i++) {
-            u64 top = t.w[3] >> 63;
-            for (int k = 3; k > 0; k--) t.w[k] = (t.w[k] << 1) | (t.w[k - 1] >> 63);
-            t.w[0] <<= 1;
-            if (top || geq(t, MOD)) sub_into(t, MOD);
-            if (i == 255) R1 = t;
-        }
-        R2 = t; ready = true;
-    }
+    static constexpr U256 R1 = pow2_mod(256, MOD), R2 = pow2_mod(512, MOD);      // 2^256, 2^512 mod MOD
+    static constexpr u64 NINV = neg_inv64(MOD.w[0]);                                // -MOD^-1 mod 2^64
+    static void init() {}      // (kept for callers: the constants are compile-time values — nothing to initialise, nothing to race on)
     static Fe zero() { return Fe{{{0, 0, 0, 0}}}; }
     static Fe one() { return Fe{R1}; }
     static Fe from_u64(u64 x) { Fe a{{{x, 0, 0, 0}}}; return a * Fe{R2}; }

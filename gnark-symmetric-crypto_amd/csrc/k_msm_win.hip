@@ -206,7 +206,7 @@ __device__ __forceinline__ Xyzz9<F> accumulate_window(const MsmWinArgs& a, size_
             // The gather is unconditional (a zero digit fetches entry 0 and drops it): a load inside a branch would have to be
             // waited for at the join, i.e. before the addition it is meant to overlap with.
             const int32_t mag = d < 0 ? -d : d;
-            const RawAff<F> e = load_raw<F>(table + ((kk + i) * D + (size_t)(mag && !a.exp_same_entry ? mag - 1 : 0)) * (2 * F::WORDS));
+            const RawAff<F> e = load_raw<F>(table + ((kk + i) * D + (size_t)(mag ? mag - 1 : 0)) * (2 * F::WORDS));
             if (dp) acc = C::template madd<EXACT>(acc, unpack_aff(pend, dp < 0));
             pend = e; dp = d;
         }
@@ -224,17 +224,11 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArg
     // (all windows, all groups of proofs) gathers from the same table rows, so a slice is placed on ONE XCD (consecutive ids there).
     const size_t G = a.batch / 64, GW = G * (size_t)a.nwin, L = blockIdx.x, S8 = a.nslices & ~(size_t)7;
     size_t slice, rem;
-    if (a.placement == 1 && (G & 3) == 0 && a.nslices >= 2) {
-        // Two slices at a time, each shared by FOUR XCDs that take a quarter of its groups of proofs: the four gather from the same
-        // rows at the same time, so a row comes from HBM once and from the Infinity Cache three times.
-        const size_t S2 = a.nslices & ~(size_t)1, Q = GW / 4;
-        if (L < S2 * GW) { const size_t xcd = L & 7, i = L >> 3; slice = (i / Q) * 2 + (xcd >> 2); rem = (xcd & 3) * Q + i % Q; }
-        else { slice = L / GW; rem = L % GW; }
-    } else if (L < S8 * GW) { const size_t xcd = L & 7, i = L >> 3; slice = (i / GW) * 8 + xcd; rem = i % GW; }
+    if (L < S8 * GW) { const size_t xcd = L & 7, i = L >> 3; slice = (i / GW) * 8 + xcd; rem = i % GW; }
     else { slice = L / GW; rem = L % GW; }
-    // consecutive workgroups of a slice: same window, consecutive groups of proofs (placement 2: same proofs, consecutive windows)
-    const uint32_t j = a.placement == 2 ? (uint32_t)(rem % (size_t)a.nwin) : (uint32_t)(rem / G);
-    const size_t p = (a.placement == 2 ? rem / (size_t)a.nwin : rem % G) * 64 + threadIdx.x;
+    // consecutive workgroups of a slice: same window, consecutive groups of proofs
+    const uint32_t j = (uint32_t)(rem / G);
+    const size_t p = (rem % G) * 64 + threadIdx.x;
     const size_t k0 = slice * a.per < a.nbases ? slice * a.per : a.nbases, k1 = k0 + a.per < a.nbases ? k0 + a.per : a.nbases;
     Xyzz9<F> acc = C::infinity();
     if (k0 < k1) {

@@ -67,16 +67,27 @@ __device__ __forceinline__ fe9 load_tw(const int32_t* tw, uint32_t ex) {
     return r;
 }
 
+// LDS tile: nine limb planes of (elements x P) words.  ds_read_b32 / ds_write_b32 serve a wave in two groups of 32 lanes = eight
+// consecutive threads-of-a-proof-quad, i.e. eight elements x P proofs, on 32 banks of 4 bytes: a group is conflict-free when its
+// eight elements fall into eight different 4-word slots (slot = element mod 8).  The butterfly stages address elements at strides
+// 1, 2, 4, 8, ... — eight lanes then differ in element bits {2,3,4}, {0,3,4}, {0,1,4}, {0,1,2} (two stages per round trip) or
+// {1,2,3}, {0,2,3}, {0,1,3} (single stages), which all land in ONE or TWO slots of a plain layout (4- and 8-way conflicts: 1.6
+// extra LDS cycles per instruction measured in round 2).  Elements are therefore stored at the swizzled position
+//   e' = e ^ (bit3(e) ? 7 : 0) ^ (bit4(e) ? 5 : 0)
+// a bijection that only changes the low three bits: as a GF(2) map of the element bits its columns are 001, 010, 100 (bits 0-2),
+// 111 (bit 3), 101 (bit 4), and every one of the seven bit triples above is linearly independent — each access pattern spreads over
+// all eight slots.  Contiguous runs (bits {0,1,2}: the global loads / stores) stay conflict-free.
+__device__ __forceinline__ uint32_t swz(uint32_t e) { return e ^ (((e >> 3) & 1u) * 7u) ^ (((e >> 4) & 1u) * 5u); }
 struct Tile {
     int32_t* lds; uint32_t plane;   // plane = elements * P (words per limb plane)
     __device__ __forceinline__ fe9 get(uint32_t e, uint32_t q) const {
-        fe9 r; const uint32_t o = e * P + q;
+        fe9 r; const uint32_t o = swz(e) * P + q;
 #pragma unroll
         for (int i = 0; i < 9; i++) r.l[i] = lds[i * plane + o];
         return r;
     }
     __device__ __forceinline__ void put(uint32_t e, uint32_t q, const fe9& v) const {
-        const uint32_t o = e * P + q;
+        const uint32_t o = swz(e) * P + q;
 #pragma unroll
         for (int i = 0; i < 9; i++) lds[i * plane + o] = v.l[i];
     }
@@ -111,7 +122,9 @@ __device__ __forceinline__ void dif_round4(const Tile& t, uint32_t u4, uint32_t 
     const uint32_t g0 = gidx<STRIDED>(e0, Llo, tile_id), g1 = gidx<STRIDED>(e1, Llo, tile_id), g2 = gidx<STRIDED>(e2, Llo, tile_id);
     const uint32_t exA = (g0 & (hg1 - 1)) << s, exB = (g1 & (hg1 - 1)) << s, exC = (g0 & (hg2 - 1)) << (s + 1), exD = (g2 & (hg2 - 1)) << (s + 1);
     const fe9 x0 = t.get(e0, q), x1 = t.get(e1, q), x2 = t.get(e2, q), x3 = t.get(e3, q);
-    const fe9 a0 = F::norm(F::add(x0, x2)), a1 = F::norm(F::add(x1, x3));
+    // tile entries are (signed-)tight: the two inner sums stay un-carried (|limb| < 2^30) — their sum (< 2^31) is carried once below,
+    // their difference (< 2^30) is a legal product operand as it is
+    const fe9 a0 = F::add(x0, x2), a1 = F::add(x1, x3);
     const fe9 a2 = mulw<false>(F::sub(x0, x2), pl.tw_inv, exA, pl.qr), a3 = mulw<false>(F::sub(x1, x3), pl.tw_inv, exB, pl.qr);
     t.put(e0, q, carry<REDUCE>(F::add(a0, a1), pl.qr));
     t.put(e1, q, mulw<REDUCE>(F::sub(a0, a1), pl.tw_inv, exC, pl.qr));
@@ -157,7 +170,7 @@ __device__ __forceinline__ void dit_round4(const Tile& t, uint32_t u4, uint32_t 
     const uint32_t exA = (g0 & m1) << (L - 1 - s), exB = (g2 & m1) << (L - 1 - s), exC = (g0 & m2) << (L - 2 - s), exD = (g1 & m2) << (L - 2 - s);
     const fe9 n0 = F::norm(t.get(e0, q)), n2 = F::norm(t.get(e2, q));
     const fe9 v1 = mulw<false>(t.get(e1, q), pl.tw_fwd, exA, pl.qr), v3 = mulw<false>(t.get(e3, q), pl.tw_fwd, exB, pl.qr);
-    const fe9 a0 = F::norm(F::add(n0, v1)), a1 = F::norm(F::sub(n0, v1));
+    const fe9 a0 = F::norm(F::add(n0, v1)), a1 = F::sub(n0, v1);      // a1: tight - tight is signed-tight as it is (|limb| < 2^29)
     const fe9 w2 = mulw<false>(F::add(n2, v3), pl.tw_fwd, exC, pl.qr), w3 = mulw<false>(F::sub(n2, v3), pl.tw_fwd, exD, pl.qr);
     t.put(e0, q, F::add(a0, w2)); t.put(e2, q, F::sub(a0, w2));
     t.put(e1, q, F::add(a1, w3)); t.put(e3, q, F::sub(a1, w3));

@@ -264,11 +264,10 @@ __device__ __forceinline__ fe readlane_fe(const fe& v, uint32_t src) {
     for (int k = 0; k < 8; k++) r.l[k] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], (int)src);
     return r;
 }
-// Wire values cross workgroups (and XCDs, each with an L2 of its own) inside one launch.  mode 1: they are read and written with
-// device-scope accesses (sc1: served at the memory side, write-through), so the barrier needs no cache maintenance; mode 0: plain
-// accesses, and the barrier writes the L2 back before arriving and invalidates it after leaving (what a cooperative grid sync does).
-__device__ __forceinline__ fe load_wire(const fe* p, bool dev) {
-    if (!dev) return load_fe(p);
+// Wire values cross workgroups (and XCDs, each with an L2 of its own) inside one launch: they are read and written with device-scope
+// accesses (sc1: loads are served at the memory side, stores write through), so no barrier has to write an L2 back or invalidate one
+// (the plain-access variant — the cooperative-groups recipe — was measured 7 % slower and started every level with a cold L2).
+__device__ __forceinline__ fe load_wire(const fe* p) {
     const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
     fe r;
 #pragma unroll
@@ -278,28 +277,32 @@ __device__ __forceinline__ fe load_wire(const fe* p, bool dev) {
     }
     return r;
 }
-__device__ __forceinline__ void store_wire(fe* p, const fe& v, bool dev) {
-    if (!dev) { store_fe(p, v); return; }
+__device__ __forceinline__ void store_wire(fe* p, const fe& v) {
     unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
 #pragma unroll
     for (int k = 0; k < 4; k++) __hip_atomic_store(q + k, (unsigned long long)v.l[2 * k] | ((unsigned long long)v.l[2 * k + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // false: the barrier was abandoned (abort bit), the caller returns
-__device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target, unsigned long long* stamps, bool dev, uint32_t poll_limit) {
+// Ordering (HSA / LLVM AMDGPU memory model, agent scope).  Producer side: every wave first waits until its own stores have been
+// acknowledged (s_waitcnt vmcnt(0): wire values are sc1 write-through stores, so "acknowledged" means they have reached the memory
+// side all XCDs share — a workgroup barrier alone does not wait for stores in flight), then the workgroup barrier collects the waves,
+// then ONE thread arrives with a RELEASE read-modify-write.  Consumer side: the poll is relaxed (no cache maintenance per poll) and
+// is followed by an ACQUIRE fence before the workgroup is let go, so no wire load of the next level can be satisfied by a line that
+// was cached before the arrivals were seen.
+__device__ __forceinline__ bool few_grid_barrier(uint32_t* sync, uint32_t target, unsigned long long* stamps, uint32_t poll_limit) {
     __shared__ uint32_t s_ok;
-    __syncthreads();                         // every wave's stores have left the CU (write-through L1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's wire stores are complete at the memory side
+    __syncthreads();
     if (threadIdx.x == 0) {
-        if (stamps) stamps[2] = wall_clock64();
-        if (!dev) __threadfence();           // release at device scope: this XCD's L2 writes back what the workgroup stored
-        if (stamps) stamps[3] = wall_clock64();
-        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stamps) stamps[2] = stamps[3] = wall_clock64();
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t polls = 0, seen;
         while ((seen = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
             if (++polls > poll_limit) { seen = __hip_atomic_fetch_or(sync, FEW_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | FEW_ABORT; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         if (stamps) stamps[4] = wall_clock64();
-        if (!dev) __threadfence();           // acquire: drop stale lines before the next level's wire loads
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (stamps) stamps[5] = wall_clock64();
         s_ok = (seen & FEW_ABORT) ? 0u : 1u;
     }
@@ -380,7 +383,6 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
     const uint32_t w0 = f.d[0], w1 = f.d[1], w2 = f.d[2], w3 = f.d[3], toff = f.d[4], n0 = f.d[5], n1 = f.d[6], n2 = f.d[7];
     const uint32_t op = w0 & 0xFF, T = n0 + n1 + n2;
     const size_t batch = a.batch;
-    const bool dev = a.coherent != 0;
     constexpr uint32_t CHUNK = 64 * FEW_SLOTS;
     fe va = Fr::zero(), vb = va, vc = va;
     const uint2* terms = reinterpret_cast<const uint2*>(a.terms) + toff;
@@ -400,7 +402,7 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
                 cid[j] = live ? cw.x : 0u;
                 const bool cst = !live || cw.y == WIRE_CONST;
                 cf[j] = load_fe(a.coeff + cid[j]);
-                x[j] = load_wire(cst ? a.coeff + 1 : a.W + (size_t)cw.y * batch + p, dev);       // one branch-free load: no early wait
+                x[j] = load_wire(cst ? a.coeff + 1 : a.W + (size_t)cw.y * batch + p);       // one branch-free load: no early wait
             }
         }
         uint32_t hard = 0;
@@ -504,7 +506,7 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
             if (uc == 3) wire = Fr::neg(wire);
             else if (uc != 1) wire = Fr::mul(wire, load_fe(a.coeff_inv + uc));
             if (stamps && lane == 0) stamps[9] = wall_clock64() + (wire.l[0] & 0u);
-            if (lane == 0) store_wire(a.W + (size_t)uw * batch + p, wire, a.coherent != 0);
+            if (lane == 0) store_wire(a.W + (size_t)uw * batch + p, wire);
         }
         {       // one store instruction for the three rows: lanes 0..2
             fe out;
@@ -525,7 +527,7 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
             fe v;
 #pragma unroll
             for (int j = 0; j < 8; j++) v.l[j] = bit ? one.l[j] : 0u;
-            if (k < w2) store_wire(a.W + (size_t)(w1 + k) * batch + p, v, a.coherent != 0);
+            if (k < w2) store_wire(a.W + (size_t)(w1 + k) * batch + p, v);
         }
     } else if (op == OP_LOOKUP) {
         const fe r = Fr::from_mont(va);
@@ -533,12 +535,12 @@ __device__ __forceinline__ void few_item(const SolverFewArgs& a, const FewFetch&
         if (hi != 0 || r.l[0] >= 256) bad = true;
         const uint32_t cid = a.lookup_coeff[w2 * 256 + (r.l[0] & 255)];
         const fe v = load_fe(a.coeff + cid);
-        if (lane == 0) store_wire(a.W + (size_t)w1 * batch + p, v, a.coherent != 0);
+        if (lane == 0) store_wire(a.W + (size_t)w1 * batch + p, v);
     } else if (op == OP_RANDOMIZE || op == OP_COMMIT) {
         const fe* src = op == OP_RANDOMIZE ? a.mask : a.commit;
         const fe v = src ? load_fe(src + p) : Fr::zero();
 #pragma unroll 1
-        for (uint32_t k = lane; k < w2; k += 64) store_wire(a.W + (size_t)(w1 + k) * batch + p, v, a.coherent != 0);
+        for (uint32_t k = lane; k < w2; k += 64) store_wire(a.W + (size_t)(w1 + k) * batch + p, v);
     }
     if (bad && lane == 0) atomicMin(a.status + p, i);
 }
@@ -547,6 +549,9 @@ template <bool HAS_DIV>
 __global__ __launch_bounds__(64 * FEW_WAVES) void k_solver_few(SolverFewArgs a) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t gw = wave * gridDim.x + blockIdx.x, nw = gridDim.x * FEW_WAVES;       // neighbouring items (the long ops come first) go to different CUs
+    // an earlier resident launch of this call gave up (sync[1], written before this launch started): the host will solve the call
+    // again level by level, so this launch must not spin through the same timeouts
+    if (__hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     uint32_t epoch = 0;
     auto op_of = [&](uint32_t l0, uint32_t it) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(l0 + it / a.n_real)); };
     uint32_t l0 = a.level_start[a.from], l1 = a.level_start[a.from + 1];
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(64 * FEW_WAVES) void k_solver_few(SolverFewArgs a) 
         if (lev + 1 == a.to) { if (stamps && threadIdx.x == 0) { a.trace[16 * a.nlev_trace + 2] = wall_clock64(); a.trace[16 * a.nlev_trace + 3] = clock64(); } break; }
         l0 = l1; l1 = a.level_start[lev + 2];
         f = few_fetch(a, op_of(l0, gw < (l1 - l0) * a.n_real ? gw : 0u), lane);            // static data of the next level's item: in flight across the barrier
-        if (!few_grid_barrier(a.sync, ++epoch * (gridDim.x + a.test_missing), stamps, a.coherent != 0, a.poll_limit)) {
+        if (!few_grid_barrier(a.sync, ++epoch * (gridDim.x + a.test_missing), stamps, a.poll_limit)) {
             if (threadIdx.x < a.n_real && blockIdx.x == 0) atomicMin(a.status + threadIdx.x, 0u);      // unsatisfied, unless the host solves the call again:
             if (threadIdx.x == 0) atomicOr(a.sync + 1, 1u);                                              // sync[1] tells it that the launch gave up
             return;

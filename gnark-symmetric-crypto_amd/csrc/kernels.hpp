@@ -59,7 +59,8 @@ struct SolverArgs {
 // executes level a.first_level, which holds `level_width` instructions
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
 // Calls with at most MSM_FEW_PROOFS statements: levels [from, to) (none of them an OP_COUNT level) in one launch of a resident grid,
-// one wave per (statement, op), lanes = terms; program layout: formats.hpp FewProgram.  sync: two words, zeroed before the launch.
+// one wave per (statement, op), lanes = terms; program layout: formats.hpp FewProgram.  sync: two words; word 0 (arrival counter) zeroed before every
+// launch, word 1 (a launch gave up at a barrier) zeroed once per call: a launch that finds it set returns at once.
 struct SolverFewArgs {
     const uint32_t* ops; const uint32_t* terms; const uint32_t* level_start;
     uint32_t from, to;
@@ -68,7 +69,6 @@ struct SolverFewArgs {
     uint32_t* status; const fe* mask; const fe* commit;
     uint32_t* sync;
     uint32_t poll_limit, test_missing;              // barrier polls before giving up; test hook: arrivals that never come (exercises the give-up path)
-    uint32_t coherent;                              // 1: wire values move with device-scope accesses, the barrier does no cache maintenance (k_solver.hip load_wire)
     uint32_t nlev_trace;                            // diagnostics: slot of the whole-launch stamps in trace (the program's level count)
     unsigned long long* trace;                      // diagnostics (GSC_SOLVER_TRACE): per level stamps of workgroup 0 (100 MHz clock: level in, first item done, workgroup done, released, all arrived, acquired), or nullptr
 };
@@ -138,9 +138,6 @@ struct MsmWinArgs {
     const uint4* digits; size_t batch;
     size_t nslices, per;           // per: a multiple of 8
     void* partial;                 // G1Xyzz / G2Xyzz [nslices][nwin][batch]
-    int placement;                 // workgroup -> (slice, window, proofs) map: 0 one XCD per slice, 1 four XCDs per slice, 2 as 0 with consecutive
-                                   // workgroups on consecutive windows instead of proofs (speed only; measured within 1 % of each other)
-    int exp_same_entry;            // MEASUREMENT ONLY (GSC_MSM_EXP=1 with test hooks on): every gather reads entry 0 — wrong sums, pure VALU time
 };
 void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s);
 void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s);

@@ -30,17 +30,30 @@ Fp fp_from_hex(const char* hex) {
     for (size_t i = 0; i < n; i++) { const char ch = hex[n - 1 - i]; const int v = ch <= '9' ? ch - '0' : (ch | 32) - 'a' + 10; b[31 - i / 2] |= (uint8_t)(v << (4 * (i & 1))); }
     Fp r; if (!Fp::from_be(b, r)) throw std::runtime_error("setup: bad constant"); return r;
 }
+// Toxic waste and everything derived from it in scalar form is overwritten before its memory is released — also when an exception
+// unwinds the stack (a HIP error, bad_alloc): secrets live in SecretVec / under a WipeOnExit guard, whose destructors do the wiping.
+void wipe_bytes(void* p, size_t n) { volatile uint8_t* q = static_cast<volatile uint8_t*>(p); for (size_t i = 0; i < n; i++) q[i] = 0; }
+void wipe(Fr& v) { wipe_bytes(v.v.w, sizeof v.v.w); }
+template <class T> struct SecretVec : std::vector<T> {
+    using std::vector<T>::vector;
+    SecretVec(const SecretVec&) = delete; SecretVec& operator=(const SecretVec&) = delete;
+    ~SecretVec() { wipe_bytes(this->data(), this->size() * sizeof(T)); }
+};
+struct WipeOnExit {      // wipes the listed scalars when the scope is left, normally or by an exception
+    std::vector<Fr*> frs;
+    explicit WipeOnExit(std::initializer_list<Fr*> l) : frs(l) {}
+    WipeOnExit(const WipeOnExit&) = delete; WipeOnExit& operator=(const WipeOnExit&) = delete;
+    ~WipeOnExit() { for (Fr* f : frs) wipe(*f); }
+};
 // One toxic scalar: hash_to_field(seed | label) — uniform in Fr up to 2^-128; never zero.
 Fr toxic(const uint8_t seed[32], const char* label) {
     uint8_t msg[64], h[48]; memcpy(msg, seed, 32); memset(msg + 32, 0, 32); strncpy((char*)msg + 32, label, 31);
     expand_message_xmd_sha256(msg, 64, "gsc-test-setup", h, 48);
     Fr t = fr_from_be_reduce(h, 48);
+    wipe_bytes(msg, sizeof msg); wipe_bytes(h, sizeof h);      // the seed and the integer that reduces to the scalar
     return t.is_zero() ? Fr::one() : t;
 }
 void fr_to_le(const Fr& v, uint8_t* out) { const U256 c = v.canon(); memcpy(out, c.w, 32); }
-// toxic waste and everything derived from it in scalar form is overwritten before the memory is released
-template <class T> void wipe(std::vector<T>& v) { volatile uint8_t* p = reinterpret_cast<volatile uint8_t*>(v.data()); for (size_t i = 0; i < v.size() * sizeof(T); i++) p[i] = 0; }
-void wipe(Fr& v) { volatile uint64_t* p = v.v.w; for (int i = 0; i < 4; i++) p[i] = 0; }
 void store_mont(const Fp& v, uint8_t* out) { memcpy(out, v.v.w, 32); }
 
 struct Out {
@@ -82,37 +95,41 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
     size_t n = 1; int lg = 0; while (n < m) { n <<= 1; lg++; }
     if (lg > 28) throw std::runtime_error("setup: constraint system too large");
     uint8_t seed[32];
+    struct SeedWipe { uint8_t* s; ~SeedWipe() { wipe_bytes(s, 32); } } seed_wipe{seed};
     if (seed32) memcpy(seed, seed32, 32);
     else { size_t got = 0; while (got < 32) { const ssize_t k = getrandom(seed + got, 32 - got, 0); if (k > 0) got += (size_t)k; else if (!(k < 0 && errno == EINTR)) throw std::runtime_error(std::string("getrandom failed: ") + strerror(errno)); } }
     Fr tau = toxic(seed, "tau"), alpha = toxic(seed, "alpha"), beta = toxic(seed, "beta"), gamma = toxic(seed, "gamma"), delta = toxic(seed, "delta"),
        sigma = toxic(seed, "sigma"), ped_g = toxic(seed, "pedersen-g");
-    { volatile uint8_t* w = seed; for (int i = 0; i < 32; i++) w[i] = 0; }
+    Fr gamma_inv = Fr::zero(), delta_inv = Fr::zero(), tn = Fr::zero(), zt = Fr::zero();
+    WipeOnExit toxic_guard{&tau, &alpha, &beta, &gamma, &delta, &sigma, &ped_g, &gamma_inv, &delta_inv, &tn, &zt};
+    wipe_bytes(seed, 32);
     // domain (gnark-crypto fft.NewDomain): generator of the 2^lg-th roots from the 2^28-th root, coset shift 5
     Fr omega = fr_from_hex("2a3c09f0a58a7e8500e0a7eb8ef62abc402d111e41112ed49bd61b6e725b19f0");
     for (int i = lg; i < 28; i++) omega = omega.sq();
     const Fr omega_inv = omega.inv(), n_inv = Fr::from_u64(n).inv(), g = Fr::from_u64(5), g_inv = g.inv(), one = Fr::one();
     // Lagrange basis at tau: L_j = (tau^n - 1) / n * w^j / (tau - w^j); one batch inversion
-    Fr tn = tau; for (int i = 0; i < lg; i++) tn = tn.sq();
-    Fr zt = tn - one;
-    std::vector<Fr> L(n);
+    tn = tau; for (int i = 0; i < lg; i++) tn = tn.sq();
+    zt = tn - one;
+    SecretVec<Fr> L(n);
     {
-        std::vector<Fr> den(n), pre(n), wj(n);
+        SecretVec<Fr> den(n), pre(n); std::vector<Fr> wj(n);
         Fr w = one;
         for (size_t j = 0; j < n; j++) { wj[j] = w; den[j] = tau - w; w = w * omega; }
-        Fr run = one; for (size_t j = 0; j < n; j++) { pre[j] = run; run = run * den[j]; }
+        Fr run = one, inv = Fr::zero(), scale = Fr::zero(), dj = Fr::zero();
+        WipeOnExit guard{&run, &inv, &scale, &dj};
+        for (size_t j = 0; j < n; j++) { pre[j] = run; run = run * den[j]; }
         if (run.is_zero()) throw std::runtime_error("setup: tau is a root of unity");
-        Fr inv = run.inv(); const Fr scale = zt * n_inv;
-        for (size_t j = n; j-- > 0;) { const Fr dj = inv * pre[j]; inv = inv * den[j]; L[j] = dj * wj[j] * scale; }
-        wipe(den); wipe(pre);
+        inv = run.inv(); scale = zt * n_inv;
+        for (size_t j = n; j-- > 0;) { dj = inv * pre[j]; inv = inv * den[j]; L[j] = dj * wj[j] * scale; }
     }
     // A_i(tau), B_i(tau), C_i(tau): column sums of the R1CS matrices against the Lagrange basis
-    std::vector<Fr> A(nw, Fr::zero()), B(nw, Fr::zero()), C(nw, Fr::zero());
+    SecretVec<Fr> A(nw, Fr::zero()), B(nw, Fr::zero()), C(nw, Fr::zero());
     std::vector<Fr> coeff(cs.n_coeff());
     for (size_t i = 0; i < coeff.size(); i++) memcpy(coeff[i].v.w, cs.coeff_limbs.data() + 8 * i, 32);      // stored in Montgomery form already
     for (size_t ii = 0; ii < cs.n_instr(); ii++) {
         if (cs.bp_kind[cs.blueprint[ii]] != BP_R1C) continue;
         const uint32_t* cd = cs.calldata.data() + cs.instr_start[ii];
-        const uint32_t cnt[3] = {cd[1], cd[2], cd[3]}; const uint32_t* t = cd + 4; std::vector<Fr>* dst[3] = {&A, &B, &C};
+        const uint32_t cnt[3] = {cd[1], cd[2], cd[3]}; const uint32_t* t = cd + 4; SecretVec<Fr>* dst[3] = {&A, &B, &C};
         if (cs.constraint_off[ii] >= m) throw std::runtime_error("setup: constraint offset out of range");
         const Fr& Lj = L[cs.constraint_off[ii]];
         for (int side = 0; side < 3; side++) for (uint32_t k = 0; k < cnt[side]; k++, t += 2) {
@@ -124,13 +141,13 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
     }
     std::vector<uint8_t> committed(nw, 0);
     for (uint32_t w : cs.commit_private) committed[w] = 1;
-    Fr gamma_inv = gamma.inv(), delta_inv = delta.inv();
+    gamma_inv = gamma.inv(); delta_inv = delta.inv();
     // ---- scalars of every G1 point of the keys, in one list:  [alpha, beta, delta | A (nw) | B (nw) | K (nw) | Z (n-1) | sigma * basis (ncp)]
     const size_t ncp = cs.commit_private.size();
     const size_t oA = 3, oB = oA + nw, oK = oB + nw, oZ = oK + nw, oS = oZ + (n - 1), n1 = oS + ncp;
-    std::vector<uint8_t> sc1(32 * n1);
+    SecretVec<uint8_t> sc1(32 * n1);
     fr_to_le(alpha, &sc1[0]); fr_to_le(beta, &sc1[32]); fr_to_le(delta, &sc1[64]);
-    std::vector<Fr> K(nw);
+    SecretVec<Fr> K(nw);
     for (size_t i = 0; i < nw; i++) {
         fr_to_le(A[i], &sc1[32 * (oA + i)]); fr_to_le(B[i], &sc1[32 * (oB + i)]);
         const bool to_vk = i < npub || (cs.has_commitment && i == cs.commit_wire) || committed[i];
@@ -138,14 +155,13 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
         fr_to_le(K[i], &sc1[32 * (oK + i)]);
     }
     {   // Z[k] = tau^bitrev(k) * Z(tau) / delta, k < n - 1
-        std::vector<Fr> tp(n); tp[0] = zt * delta_inv; for (size_t j = 1; j < n; j++) tp[j] = tp[j - 1] * tau;
+        SecretVec<Fr> tp(n); tp[0] = zt * delta_inv; for (size_t j = 1; j < n; j++) tp[j] = tp[j - 1] * tau;
         for (size_t k = 0; k + 1 < n; k++) { size_t br = 0; for (int b = 0; b < lg; b++) if ((k >> b) & 1) br |= (size_t)1 << (lg - 1 - b); fr_to_le(tp[br], &sc1[32 * (oZ + k)]); }
-        wipe(tp);
     }
     for (size_t j = 0; j < ncp; j++) fr_to_le(K[cs.commit_private[j]] * sigma, &sc1[32 * (oS + j)]);
     // ---- G2: [beta, gamma, delta | B (nw) | pedersen G, -sigma * G]
     const size_t o2B = 3, o2P = o2B + nw, n2 = o2P + 2;
-    std::vector<uint8_t> sc2(32 * n2);
+    SecretVec<uint8_t> sc2(32 * n2);
     fr_to_le(beta, &sc2[0]); fr_to_le(gamma, &sc2[32]); fr_to_le(delta, &sc2[64]);
     for (size_t i = 0; i < nw; i++) memcpy(&sc2[32 * (o2B + i)], &sc1[32 * (oB + i)], 32);
     fr_to_le(ped_g, &sc2[32 * o2P]); fr_to_le((ped_g * sigma).neg(), &sc2[32 * (o2P + 1)]);
@@ -159,9 +175,11 @@ SetupKeys groth16_setup(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* see
     std::vector<uint8_t> p1(64 * n1), i1(n1), p2(128 * n2), i2(n2);
     setup_generator_muls(device, false, g1m, sc1.data(), n1, p1.data(), i1.data());
     setup_generator_muls(device, true, g2m, sc2.data(), n2, p2.data(), i2.data());
-    // from here on only group elements are needed: discard the toxic waste and every scalar derived from it
-    wipe(sc1); wipe(sc2); wipe(L); wipe(A); wipe(B); wipe(C); wipe(K);
-    for (Fr* f : {&tau, &alpha, &beta, &gamma, &delta, &sigma, &ped_g, &gamma_inv, &delta_inv, &tn, &zt}) wipe(*f);
+    // from here on only group elements are needed: discard the toxic waste and every scalar derived from it now (the guards above
+    // would do it at the end of the function, and do it on any early exit)
+    for (SecretVec<uint8_t>* v : {&sc1, &sc2}) wipe_bytes(v->data(), v->size());
+    for (SecretVec<Fr>* v : {&L, &A, &B, &C, &K}) wipe_bytes(v->data(), v->size() * sizeof(Fr));
+    for (Fr* f : toxic_guard.frs) wipe(*f);
     auto g1 = [&](Out& o, size_t idx) { put_g1(o, &p1[64 * idx], i1[idx] != 0); };
     auto g2 = [&](Out& o, size_t idx) { put_g2(o, &p2[128 * idx], i2[idx] != 0); };
     auto in_pkK = [&](size_t i) { return i >= npub && !committed[i] && !(cs.has_commitment && i == cs.commit_wire); };

@@ -10,10 +10,10 @@ namespace gsc {
 
 namespace {
 struct Buf {
-    void* p = nullptr;
-    explicit Buf(size_t bytes) { HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1)); }
+    void* p = nullptr; size_t bytes = 0; bool secret = false;      // secret: zeroed before it is freed, also when an exception unwinds
+    explicit Buf(size_t n, bool is_secret = false) : bytes(n ? n : 1), secret(is_secret) { HIP_CHECK(hipMalloc(&p, bytes)); }
     Buf(const Buf&) = delete; Buf& operator=(const Buf&) = delete;
-    ~Buf() { if (p) (void)hipFree(p); }
+    ~Buf() { if (p) { if (secret) { (void)hipMemset(p, 0, bytes); (void)hipDeviceSynchronize(); } (void)hipFree(p); } }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -34,14 +34,13 @@ void run(const uint8_t* gen_mont, const uint8_t* scalars_le, size_t n, uint8_t* 
     HIP_CHECK(hipMemcpy(d_segs.p, segs.data(), sizeof(MsmRowSeg) * segs.size(), hipMemcpyHostToDevice));
     build(bases.as<AffT>(), d_segs.as<MsmRowSeg>(), segs.size(), cap, table.as<AffT>(), scratch.as<XyzzT>(), s);
     HIP_CHECK(hipGetLastError());
-    Buf d_sc(32 * n), d_out(sizeof(AffT) * n), d_inf(n);
+    Buf d_sc(32 * n, true), d_out(sizeof(AffT) * n), d_inf(n);      // the scalars are toxic waste in disguise: never left in freed device memory
     HIP_CHECK(hipMemcpy(d_sc.p, scalars_le, 32 * n, hipMemcpyHostToDevice));
     mul(table.as<AffT>(), c, nwin, d_sc.as<fe>(), n, d_out.as<fe>(), d_inf.as<uint8_t>(), s);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out, d_out.p, sizeof(AffT) * n, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(inf, d_inf.p, n, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemset(d_sc.p, 0, 32 * n));      // the scalars are toxic waste in disguise: do not leave them in freed device memory
 }
 }  // namespace
 

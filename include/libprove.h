@@ -91,13 +91,17 @@ extern long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t *abc_be,
  * flags (bit 0: k1 < 0, bit 1: k2 < 0) with k = k1 + k2 * lambda (mod r).  Returns 0, -1 on error. */
 extern int gsc_debug_glv_split(const uint8_t *k, uint8_t *out);
 
-/* Human-readable description of an initialised algorithm (sizes, table memory); returns bytes written. */
+/* Human-readable description of an initialised algorithm (sizes, table memory, and per engine replica of GSC_DEVICES the calls /
+ * statements it has served so far: "served(calls/statements)=a/b,c/d"); returns bytes written. */
 extern size_t gsc_describe(GoUint8 algorithmID, char *out, size_t cap);
-/* Device milliseconds of the four stages (witness, quotient, msm, assembly) of the last batch of that algorithm. */
+/* Device milliseconds of the four stages (witness, quotient, msm, assembly) of the batch of that algorithm that finished last. */
 extern int gsc_last_stage_ms(GoUint8 algorithmID, float out[4]);
-/* HIP-event milliseconds of the dominant kernel (Z-table MSM gather-accumulate) in the last batch; *batch = proofs the
- * launch covered (padded to 64), *nbases = fixed bases per proof.  Used by bench.py for the roofline line. */
-extern float gsc_last_msm_z_kernel_ms(GoUint8 algorithmID, size_t *batch, size_t *nbases);
+/* The dominant kernel of the batch of that algorithm that finished last, timed with HIP events on the kernel's own stream (bench.py's
+ * roofline object).  Batch calls: "k_msm_win<Fp29f>", the Z-table gather-accumulate.  Calls of a handful of statements (the latency
+ * path): the resident witness kernel "k_solver_few".  name: NUL-terminated kernel name (cap bytes); *ms: milliseconds; *statements:
+ * statements the call proved; *columns: the 64-padded batch the kernels ran on; *nbases: fixed bases per proof of the Z set.
+ * Any out pointer may be NULL.  Returns 0, -1 when the algorithm is not initialised. */
+extern int gsc_last_dominant_kernel(GoUint8 algorithmID, char *name, size_t cap, float *ms, size_t *statements, size_t *columns, size_t *nbases);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,95 @@
+"""The engine configuration bench.py TIMES is a tested configuration ("parity gate for every timed configuration";
+the reference's own gate is libraries/core_test.go:171).
+
+The rest of the GPU session runs with small tables (conftest.py: GSC_Z_TABLE_GB=24 -> Z digits of c = 14, lanes of 1024 proofs).  The
+driver's bench runs bench.engine_env("chacha20", 8192): c = 16 — the int16 edge of the digit recoder (digits in [-2^15, 2^15 - 1], row
+index 2^15 - 1) —, 69 GB of Z rows, one lane of 8192 proofs, 128 slices x 16 windows x 128 proof groups.  This test starts a prover
+process with exactly that environment, proves 8192 statements in one call with (r, s) fixed, compares eight of them byte for byte
+with the CPU oracle (first / last wave and the wave boundaries 63 | 64, 4095 | 4096, 8127 | 8128) and verifies ALL of them with
+libverify.so under the reference's vk.chacha20.
+
+The file sorts before every other GPU test: its child process needs ~125 GB of the device, which the session's own algorithms
+(~170 GB once the AES tests have run) would not leave."""
+import base64
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from conftest import ROOT, golden_bytes
+
+pytestmark = pytest.mark.gpu
+
+_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import bench, gsc_loader
+import torch
+free, total = torch.cuda.mem_get_info(0)
+assert free > 135e9, "the bench configuration needs ~125 GB of device memory; only %.0f GB are free (run this test before the session loads its own algorithms)" % (free / 1e9)
+g = gsc_loader.load()
+assert g.init_algorithm(0, bench.golden("pk.chacha20"), bench.golden("r1cs.chacha20"))
+d = g.describe(0)
+print("DESCRIBE", d)
+assert "window_z=16 " in d and "max_batch=8192 " in d and "lanes=1 " in d, d
+n = 8192
+recs = bench.xoshiro_records(n, 0x7E57 << 20)
+g.set_deterministic_randomness(int(sys.argv[3]), int(sys.argv[4]), 0)
+ok, proofs, lens, cts = g.prove_raw(0, recs, n)
+assert ok == n and set(lens) == {164}, (ok, set(lens))
+name, ms, stmts, cols, nb = g.last_dominant_kernel(0)
+assert name.startswith("k_msm_win") and stmts == n and cols == n and nb == 32767, (name, stmts, cols, nb)
+open(sys.argv[2], "wb").write(recs + proofs + cts)
+print("CHILD-OK")
+"""
+
+
+def test_the_timed_configuration_proves_8192_statements_bit_exactly(gsc, oracle, chacha_oracle, tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    n = 8192
+    r, s = 0x1234567, 0xabcdef0123456789abcdef
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GSC_")}
+    env.update(bench.engine_env("chacha20", n))                 # exactly what `python bench.py` sets before it loads the library
+    env["GSC_ENABLE_TEST_HOOKS"] = "1"                          # fixed (r, s): what byte-level parity is defined on
+    out_path = str(tmp_path / "out.bin")
+    p = subprocess.run([sys.executable, "-c", _CHILD, ROOT, out_path, str(r), str(s)], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "CHILD-OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+    blob = open(out_path, "rb").read()
+    recs, proofs, cts = blob[:112 * n], blob[112 * n:112 * n + 196 * n], blob[112 * n + 196 * n:]
+    assert len(cts) == 64 * n and recs == bench.xoshiro_records(n, 0x7E57 << 20)
+    # byte for byte against the oracle (pinned by the reference's App. E vectors and vk.chacha20: tests/test_oracle.py)
+    cs, pk, vk = chacha_oracle
+    for k in (0, 63, 64, 4095, 4096, 8127, 8128, 8191):
+        rec = recs[112 * k:112 * (k + 1)]
+        want, want_ct = oracle.prove(cs, pk, "chacha20", rec[:32], rec[32:44], int.from_bytes(rec[44:48], "little"), rec[48:], r, s)
+        assert cts[64 * k:64 * k + 64] == want_ct, k
+        assert proofs[196 * k:196 * k + 164] == want, k
+    # every proof through the product's verifier under the reference's verifying key
+    assert gsc.init_verifier(0, golden_bytes("vk.chacha20"))
+
+    def check(k):
+        rec = recs[112 * k:112 * (k + 1)]
+        return gsc.verify({"cipher": "chacha20", "proof": base64.b64encode(proofs[196 * k:196 * k + 164]).decode(),
+                           "publicSignals": base64.b64encode(bench.signals_of("chacha20", rec, cts[64 * k:64 * k + 64])).decode()})
+    with ThreadPoolExecutor(min(32, len(os.sched_getaffinity(0)))) as pool:
+        res = list(pool.map(check, range(n)))
+    assert all(res), [k for k, v in enumerate(res) if not v][:10]
+    assert len({proofs[196 * k:196 * k + 164] for k in range(n)}) == n
+
+
+def test_bench_verifies_its_own_proofs_and_reports_it(tmp_path):
+    # bench.py itself, small (a batch of 256 at the session's table budget): the JSON line must carry "verified" and the roofline
+    # bookkeeping of the launch it timed; a run whose proofs do not verify exits non-zero (bench.py: "REJECTED").
+    import json
+    env = dict(os.environ)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "256", "--verify", "64", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["verified"] == 64 and line["n_gpus"] == 1 and line["config"]["batch_per_gpu"] == 256
+    rf = line["roofline"]
+    assert rf["proofs_per_launch"] == 256 and rf["kernel"].startswith("k_msm_win") and rf["algorithmic_bytes_per_launch"] == 256 * 32767 * 96
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and "traffic_source" in rf

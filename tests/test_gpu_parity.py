@@ -228,7 +228,8 @@ def test_engine_options_do_not_change_the_proofs():
     base = _digest({})
     # GSC_DEVICES=0,0: two engine replicas (here both on the one device of the box), every batch split between them — the in-library
     # multi-GPU path of a single FFI host process.
-    for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_MSM_PLACEMENT": "1"}, {"GSC_DEVICES": "0,0"}):
+    for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_DEVICES": "0,0"}, {"GSC_WINDOW_Z": "11", "GSC_MIN_SPLIT": "512"},
+                  {"GSC_WINDOW_Z": "0", "GSC_Z_TABLE_GB": "1", "GSC_LINGER_US": "0"}):
         assert _digest(extra) == base, extra
 
 
@@ -237,7 +238,7 @@ def test_engine_options_do_not_change_the_proofs_aes(aes_keys):
     pk_path = os.path.join(ROOT, "build", "keys", "pk.aes128")
     assert os.path.exists(pk_path)
     base = _digest({}, 1, pk_path)
-    for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_ROW_MARGIN_BITS": "-6"}):
+    for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_ROW_MARGIN_BITS": "-6"}, {"GSC_WINDOW_W": "9"}):
         assert _digest(extra, 1, pk_path) == base, extra
 
 
@@ -246,7 +247,7 @@ def test_latency_path_options_do_not_change_the_proofs(aes_keys, algo, counts):
     # Calls with a handful of statements (GSC_FEW_MAX: 32 ChaCha20, 20 AES) take kernels of their own (resident lanes-are-terms solver with device-wide barriers, flat and
     # windowed MSMs with lanes = bases, the quotient bases as (base, window) rows without a Horner pass, A / B1 sums early on the side
     # stream).  With (r, s, mask) fixed, a handful of statements must give the same bytes as the batch kernels (GSC_FEW_PATH=0
-    # GSC_FEW_SOLVER=0), whatever the grid, the barrier's memory mode, the quotient layout and the latency rows of the wide wires (GSC_FEW_WIDE).
+    # GSC_FEW_SOLVER=0), whatever the grid, the quotient layout and the latency rows of the wide wires (GSC_FEW_WIDE).
     from conftest import ROOT
     pk_path = os.path.join(ROOT, "build", "keys", "pk.aes128") if algo else None
     small = {"GSC_MAX_BATCH": "64", "GSC_LANES": "1"}
@@ -254,8 +255,8 @@ def test_latency_path_options_do_not_change_the_proofs(aes_keys, algo, counts):
         base = _digest(dict(small, TEST_STATEMENTS=n, GSC_FEW_PATH="0", GSC_FEW_SOLVER="0"), algo, pk_path)
         # quotient layout budgets: ChaCha20 8-bit rows (8.6 GB) and 6-bit ones (2.9 GB); AES 4-bit rows (4.3 GB: the session's own algorithms hold most of the device)
         z, z2 = ("12", "3") if algo == 0 else ("5", "5")
-        for extra in ({"GSC_FEW_Z_GB": z, "GSC_FEW_WIDE": "1"}, {"GSC_FEW_Z_GB": "0"}, {"GSC_FEW_Z_GB": z, "GSC_FEW_COHERENT": "0", "GSC_FEW_WGS": "17"},
-                      {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": z2, "GSC_FEW_WIDE": "1"}):
+        for extra in ({"GSC_FEW_Z_GB": z, "GSC_FEW_WIDE": "1"}, {"GSC_FEW_Z_GB": "0"}, {"GSC_FEW_Z_GB": z, "GSC_FEW_WGS": "17"},
+                      {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": z2, "GSC_FEW_WIDE": "1"}, {"GSC_FEW_MAX": "2", "GSC_FEW_Z_GB": z2}):
             assert _digest(dict(small, TEST_STATEMENTS=n, **extra), algo, pk_path) == base, (n, extra)
 
 
