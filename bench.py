@@ -239,6 +239,36 @@ def _cpu_worker(args):
     return time.time() - t
 
 
+def usable_cores():
+    """(cores this process can actually keep busy, how that was found): the scheduler affinity, cut down to the container's CPU quota
+    (cgroup v2 cpu.max / v1 cfs quota) — a GPU box shows all 256 host threads in the affinity mask while the job's share is 16."""
+    n = len(os.sched_getaffinity(0)); how = "affinity mask"
+    for path, v2 in (("/sys/fs/cgroup/cpu.max", True), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", False)):
+        try:
+            if v2:
+                quota, period = open(path).read().split()[:2]
+            else:
+                quota, period = open(path).read().strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1") and int(period) > 0:
+                q = max(1, int(int(quota) / int(period)))
+                if q < n:
+                    n, how = q, "cgroup CPU quota %s/%s" % (quota, period)
+                break
+        except (OSError, ValueError):
+            pass
+    if how == "affinity mask":
+        # no quota visible: a GPU box is one slot of a shared host (its share is 16 cores per GPU); oversubscribing it measures the
+        # neighbours' load, not the port (256 workers there: 17 proofs/s against 31 with 16)
+        try:
+            import torch
+            share = 16 * max(1, torch.cuda.device_count())
+            if torch.cuda.device_count() and share < n:
+                n, how = share, "16 cores per visible GPU (shared host, no CPU quota visible; affinity mask %d)" % len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+    return n, how
+
+
 def cpu_baseline(workload, cores):
     """Oracle (CPU port of the same path) on `cores` host cores: independent single-threaded provers, one per core, on a bounded
     sample of the same workload (about 10-30 s of CPU work)."""
@@ -483,7 +513,7 @@ def main():
             recs = inputs_of[last_id]; cipher = ALGOS[workload][1]; proofs, cts = pb.raw, cb.raw
             for k in sample_indices(BT, args.verify, edges):
                 items.append((cipher, proofs[196 * k:196 * k + plen], signals_of(workload, recs[112 * k:112 * (k + 1)], cts[64 * k:64 * k + 64])))
-        res = verify_items(g, items, threads=min(32, len(os.sched_getaffinity(0))))
+        res = verify_items(g, items, threads=min(32, 2 * usable_cores()[0]))
         if not all(res):
             raise SystemExit("bench.py: rank %d: %d of %d sampled proofs of the last timed step were REJECTED by libverify.so" % (rank, res.count(False), len(res)))
         # a proof must not verify for a neighbour's statement (the verifier is not a rubber stamp)
@@ -533,13 +563,15 @@ def main():
             if len(roofs) > 1:
                 line["roofline_per_algorithm"] = roofs
             if ngpu == 1 and not args.no_cpu_baseline:
-                host_cores = os.cpu_count() or 1
-                cores = args.cpu_cores or len(os.sched_getaffinity(0))       # every core this process may run on ("all host cores")
+                # "all host cores"  = every core this job may keep busy: the affinity mask cut down to the container's CPU quota
+                quota_cores, how = usable_cores()
+                cores = args.cpu_cores or quota_cores
                 try:
                     line["cpu_baseline"] = cpu_baseline(workload, cores)
                 except Exception as e:      # the baseline is reported, never required for the GPU number
                     line["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
-                line["cpu_baseline"]["host_cores"] = host_cores
+                line["cpu_baseline"]["host_cores"] = os.cpu_count() or 1
+                line["cpu_baseline"]["cores_from"] = how
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:

@@ -82,6 +82,8 @@ EngineConfig config_from_env() {
     }
     c.max_batch = (size_t)env_int("GSC_MAX_BATCH", 1024);
     c.lanes = env_int("GSC_LANES", 0);
+    c.small_lanes = env_int("GSC_SMALL_LANES", -1);
+    if (c.small_lanes > 8) throw std::runtime_error("GSC_SMALL_LANES must be at most 8");
     c.min_split = (size_t)env_int("GSC_MIN_SPLIT", 256);
     c.bit_groups = env_int("GSC_BIT_GROUPS", 1);
     c.window_z = env_int("GSC_WINDOW_Z", 0);
@@ -112,6 +114,15 @@ EngineConfig config_from_env() {
 struct FewSolverChain { std::mutex m; hipEvent_t last = nullptr; };
 static FewSolverChain& few_solver_chain(int device) { static FewSolverChain* chains = new FewSolverChain[64]; return chains[device & 63]; }      // never destroyed: lanes may outlive static destructors
 
+// The quotient transforms and the MSMs of a big batch fill the chip on their own (VALU-bound); two of them side by side only thrash each
+// other's table gathers (measured in round 2: two lanes no faster than one).  What does overlap is the witness stage — bound by HBM
+// traffic and dependent levels, not by VALU issue — with ANOTHER batch's transforms and MSMs.  So the heavy phases of big batches are
+// chained per device, in enqueue order, with events (no host blocking), across lanes and algorithms: while one lane computes, the
+// other lane's next batch is solved.
+struct HeavyChain { std::mutex m; hipEvent_t last = nullptr; };
+static HeavyChain& heavy_chain(int device) { static HeavyChain* chains = new HeavyChain[64]; return chains[device & 63]; }
+constexpr size_t HEAVY_MIN_BATCH = 1024;      // smaller batches leave the chip under-filled in every stage: they run freely side by side
+
 class AlgorithmImpl {
   public:
     Cipher cipher; EngineConfig cfg;
@@ -119,10 +130,18 @@ class AlgorithmImpl {
     bool has_commitment = false;
     // lanes are handed out one chunk at a time; concurrent calls (and the chunks of one call) take whichever lane is free
     std::mutex pool_mu; std::condition_variable pool_cv; std::vector<uint8_t> lane_busy;
-    size_t acquire_lane(int want = -1) {
+    // a free lane that can hold n statements — the smallest such lane, so that small calls leave the full-capacity lanes to big ones
+    size_t acquire_lane(int want = -1, size_t n = 0) {
         std::unique_lock<std::mutex> l(pool_mu);
         size_t got = 0;
-        pool_cv.wait(l, [&] { for (size_t i = 0; i < lane_busy.size(); i++) if (!lane_busy[i] && (want < 0 || (size_t)want == i)) { got = i; return true; } return false; });
+        pool_cv.wait(l, [&] {
+            bool found = false;
+            for (size_t i = 0; i < lane_busy.size(); i++) {
+                if (lane_busy[i] || (want >= 0 && (size_t)want != i) || lanes[i]->cap < n) continue;
+                if (!found || lanes[i]->cap < lanes[got]->cap) { got = i; found = true; }
+            }
+            return found;
+        });
         lane_busy[got] = 1;
         return got;
     }
@@ -154,6 +173,7 @@ class AlgorithmImpl {
         hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;      // side: the assembly's scalar multiplications, beside the MSMs; side2: the B2 sum of a latency-path call
         hipEvent_t ev_ab = nullptr, ev_fs = nullptr, ev_b2 = nullptr, ev_s2 = nullptr;
         hipEvent_t ev_few = nullptr;    // completion of this lane's latest k_solver_few launch (FewSolverChain)
+        hipEvent_t ev_heavy = nullptr;  // completion of this lane's latest transforms + MSMs (HeavyChain)
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
@@ -171,11 +191,14 @@ class AlgorithmImpl {
         DevBuf<G1Xyzz> d_sj1[NSETS], d_flat1[NSETS]; DevBuf<G2Xyzz> d_sj2, d_flat2;
         MsmHornerJobs pending1{}, pending2{};
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
-        ~Lane() { if (ev_few) { for (int d = 0; d < 64; d++) { FewSolverChain& c = few_solver_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_few) c.last = nullptr; } (void)hipEventDestroy(ev_few); }
+        ~Lane() { if (ev_heavy) { for (int d = 0; d < 64; d++) { HeavyChain& c = heavy_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_heavy) c.last = nullptr; } (void)hipEventDestroy(ev_heavy); }
+                  if (ev_few) { for (int d = 0; d < 64; d++) { FewSolverChain& c = few_solver_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_few) c.last = nullptr; } (void)hipEventDestroy(ev_few); }
                   for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (ev_b2) (void)hipEventDestroy(ev_b2); if (ev_s2) (void)hipEventDestroy(ev_s2); if (side2) (void)hipStreamDestroy(side2); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;
-    size_t cap = 0;                     // proofs per lane = the largest chunk
+    size_t cap = 0;                     // proofs per full lane = the largest chunk
+    size_t full_lanes = 0;              // lanes [0, full_lanes) hold `cap` proofs; the rest are small lanes (SMALL_LANE_CAP)
+    static constexpr size_t SMALL_LANE_CAP = 512;
 
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf) : cipher(c), cfg(cf) {
         // measured crossover with the batch kernels (one 64-column batch: 12.9 ms ChaCha20, 43.7 ms AES): 32 statements for ChaCha20 (10.2 ms), ~23 for AES (8.2 ms + 1.6 ms each: 38.4 ms for 20)
@@ -205,9 +228,17 @@ class AlgorithmImpl {
         if (cfg.lanes <= 0) cfg.lanes = has_commitment ? 2 : 1;
         const size_t nl = (size_t)cfg.lanes, lane_cap = (cfg.max_batch + 63) / 64 * 64;
         for (size_t i = 0; i < nl; i++) { lanes.emplace_back(new Lane); alloc_lane(*lanes.back(), lane_cap); }
-        lane_busy.assign(nl, 0);
+        full_lanes = nl;
+        // Small lanes: calls of a few dozen to a few hundred statements leave the chip under-filled in every stage (163 dependent solver
+        // levels of ~26 us, Horner and scalar-multiplication chains that do not shrink with the batch), so several of them must be in
+        // flight at once — without paying a full lane's memory for each (46 GB at 8192 proofs): extra lanes of SMALL_LANE_CAP proofs
+        // (~3 GB each for ChaCha20-V3), taken by calls that fit them.  GSC_SMALL_LANES: default 2 for ChaCha20-V3; AES-V2 has two full lanes already.
+        if (cfg.small_lanes < 0) cfg.small_lanes = has_commitment ? 0 : 2;
+        const size_t small_cap = lane_cap > SMALL_LANE_CAP ? SMALL_LANE_CAP : lane_cap;
+        for (int i = 0; i < cfg.small_lanes; i++) { lanes.emplace_back(new Lane); alloc_lane(*lanes.back(), small_cap); }
+        lane_busy.assign(lanes.size(), 0);
         cap = lane_cap;
-        if (trace) fprintf(stderr, "InitAlgorithm(%d): %zu lane(s) of %zu proofs %.0f ms\n", (int)c, nl, lane_cap, ms(t3, now()));
+        if (trace) fprintf(stderr, "InitAlgorithm(%d): %zu lane(s) of %zu proofs + %d of %zu, %.0f ms\n", (int)c, nl, lane_cap, cfg.small_lanes, small_cap, ms(t3, now()));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
     ~AlgorithmImpl() { lanes.clear(); if (stream) (void)hipStreamDestroy(stream); }
@@ -536,7 +567,7 @@ class AlgorithmImpl {
         ln.cap = B;
         HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side)); HIP_CHECK(hipStreamCreate(&ln.side2));
         for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
-        HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_heavy, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
         ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2); ln.d_glv.alloc(2 * MSM_FEW_PROOFS);
         ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
@@ -843,6 +874,12 @@ class AlgorithmImpl {
             HIP_CHECK(hipEventRecord(ln.ev_s2, ln.side2));
         }
         // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
+        std::unique_lock<std::mutex> heavy_lock;      // held while the heavy phase is ENQUEUED: the chain's order is the enqueue order
+        HeavyChain& hchain = heavy_chain(cfg.device);
+        if (B >= HEAVY_MIN_BATCH) {
+            heavy_lock = std::unique_lock<std::mutex>(hchain.m);
+            if (hchain.last && hchain.last != ln.ev_heavy) HIP_CHECK(hipStreamWaitEvent(ln.stream, hchain.last, 0));
+        }
         NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
         HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
         HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, ln.n_real <= (size_t)cfg.few_max && cfg.few_path ? ln.n_real : 0));      // latency path: the statements' columns only
@@ -872,6 +909,7 @@ class AlgorithmImpl {
         if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
         HIP_CHECK(hipGetLastError());      // MSM launches
         HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
+        if (heavy_lock.owns_lock()) { HIP_CHECK(hipEventRecord(ln.ev_heavy, ln.stream)); hchain.last = ln.ev_heavy; heavy_lock.unlock(); }
         // 4. assembly
         HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_fs, 0));
         if (early_b2) HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_s2, 0));
@@ -979,7 +1017,7 @@ Algorithm::~Algorithm() = default;
 Cipher Algorithm::cipher() const { return impls_[0]->cipher; }
 size_t Algorithm::max_batch() const { size_t c = 0; for (auto& i : impls_) c += i->cap; return c; }
 size_t Algorithm::devices() const { return impls_.size(); }
-size_t Algorithm::lanes() const { return impls_[0]->lanes.size(); }
+size_t Algorithm::lanes() const { return impls_[0]->lanes.size(); }      // full + small: device batches that can be in flight per device
 KernelStat Algorithm::last_kernel_stat() const {
     AlgorithmImpl* a = impls_[last_replica_.load() < impls_.size() ? last_replica_.load() : 0].get();
     std::lock_guard<std::mutex> lk(a->stat_mu);
@@ -988,8 +1026,8 @@ KernelStat Algorithm::last_kernel_stat() const {
 std::string Algorithm::describe() const {
     const AlgorithmImpl* impl_ = impls_[0].get();
     char buf[640];
-    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu devices=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu grouped A=%zu B=%zu K=%zu wide(windowed+expanded) A=%zu+%zu B=%zu+%zu K=%zu+%zu",
-             impl_->n_wires, impl_->n_constraints, impl_->L, max_batch(), impl_->lanes.size(), impls_.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
+    snprintf(buf, sizeof buf, "wires=%zu constraints=%zu domain=2^%d max_batch=%zu lanes=%zu small=%zux%zu devices=%zu window_z=%d window_w=%d tables=%.2f GiB bases A=%zu B=%zu K=%zu Z=%zu grouped A=%zu B=%zu K=%zu wide(windowed+expanded) A=%zu+%zu B=%zu+%zu K=%zu+%zu",
+             impl_->n_wires, impl_->n_constraints, impl_->L, max_batch(), impl_->full_lanes, impl_->lanes.size() - impl_->full_lanes, impl_->lanes.size() > impl_->full_lanes ? impl_->lanes.back()->cap : (size_t)0, impls_.size(), impl_->cfg.window_z, impl_->cfg.window_w, impl_->table_bytes / 1073741824.0,
              impl_->mA.nbases, impl_->mB1.nbases, impl_->mK.nbases, impl_->mZ.nbases, impl_->mA.nbit, impl_->mB1.nbit, impl_->mK.nbit,
              impl_->mA.nwide, impl_->mA.nexpanded, impl_->mB1.nwide, impl_->mB1.nexpanded, impl_->mK.nwide, impl_->mK.nexpanded);
     // per replica: calls and statements it has served (ReplicaPicker): shows that small calls reach every device
@@ -1023,7 +1061,7 @@ void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out)
 // calls are in flight it stays whole and the overlap happens between calls instead (measured on AES-128, two callers: +4 %).
 static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
     if (!n) return;
-    const size_t nl = a.lanes.size(), lane_cap = a.lanes[0]->cap;
+    const size_t nl = a.full_lanes, lane_cap = a.lanes[0]->cap;      // only full lanes take the chunks of a big call
     size_t nchunks = (n + lane_cap - 1) / lane_cap;
     struct InFlight { std::atomic<int>& c; int seen; explicit InFlight(std::atomic<int>& x) : c(x), seen(x.fetch_add(1) + 1) {} ~InFlight() { c.fetch_sub(1); } } me(a.calls_in_flight);
     if (nl > 1 && me.seen == 1 && n >= 2 * a.cfg.min_split) { const size_t want = (nchunks + nl - 1) / nl * nl; nchunks = want; }
@@ -1039,7 +1077,7 @@ static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t 
                 const size_t c = next.fetch_add(1);
                 if (c >= nchunks) break;
                 const size_t off = c * chunk, take = n - off < chunk ? n - off : chunk;
-                struct Hold { AlgorithmImpl& a; size_t i; ~Hold() { a.release_lane(i); } } hold{a, a.acquire_lane()};
+                struct Hold { AlgorithmImpl& a; size_t i; ~Hold() { a.release_lane(i); } } hold{a, a.acquire_lane(-1, take)};
                 a.prove_chunk(*a.lanes[hold.i], reqs + off, take, results + off, off == 0 ? debug_first : nullptr);
             }
         } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
