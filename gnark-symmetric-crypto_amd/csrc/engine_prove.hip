@@ -1,0 +1,370 @@
+// Per-batch half of the engine: witness -> quotient -> MSMs -> assembly for one chunk of statements on one lane (prove_chunk), the
+// MSM orchestration (run_msm) and proof serialisation.  See engine_impl.hpp; reference: groth16.Prove + proof.WriteTo behind
+// libraries/prover/impl/provers.go:148-157, :216-226.
+#include "engine_impl.hpp"
+#include "glv.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+namespace gsc {
+
+FewSolverChain& few_solver_chain(int device) { static FewSolverChain* chains = new FewSolverChain[64]; return chains[device & 63]; }
+HeavyChain& heavy_chain(int device) { static HeavyChain* chains = new HeavyChain[64]; return chains[device & 63]; }
+
+namespace {
+// (p-1)/2, big-endian: a compressed point carries the "larger y" flag iff y > (p-1)/2
+const uint8_t kHalfP[32] = {0x18, 0x32, 0x27, 0x39, 0x70, 0x98, 0xd0, 0x14, 0xdc, 0x28, 0x22, 0xdb, 0x40, 0xc0, 0xac, 0x2e,
+                            0xcb, 0xc0, 0xb5, 0x48, 0xb4, 0x38, 0xe5, 0x46, 0x9e, 0x10, 0x46, 0x0b, 0x6c, 0x3e, 0x7e, 0xa3};
+
+void le_limbs_to_be(const uint8_t* le, uint8_t* be) { for (int i = 0; i < 32; i++) be[i] = le[31 - i]; }
+bool be_greater(const uint8_t* a, const uint8_t* b) { int c = memcmp(a, b, 32); return c > 0; }
+bool be_is_zero(const uint8_t* a) { for (int i = 0; i < 32; i++) if (a[i]) return false; return true; }
+}  // namespace
+
+template <class XyzzT, class LR>
+void AlgorithmImpl::reduce_slices(hipStream_t st, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, XyzzT* out, LR launch_reduce) {
+    XyzzT* src = pa; XyzzT* alt = pb; size_t ns = nslices;
+    for (;;) {
+        const size_t groups = msm_reduce_groups(ns, cols);
+        XyzzT* dst = groups == 1 ? out : alt;
+        launch_reduce(src, ns, cols, dst, st);
+        if (groups == 1) break;
+        XyzzT* t = src; src = dst; alt = t; ns = groups;
+    }
+}
+
+template <class XyzzT, class LRF>
+void AlgorithmImpl::reduce_slices_few(hipStream_t st, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, size_t stride, size_t npr, XyzzT* out, LRF launch_reduce_few) {
+    XyzzT* src = pa; XyzzT* alt = pb; size_t ns = nslices;
+    for (;;) {
+        const size_t groups = (ns + 63) / 64;
+        XyzzT* dst = groups == 1 ? out : alt;
+        launch_reduce_few(src, ns, cols, stride, npr, dst, st);
+        if (groups == 1) break;
+        XyzzT* t = src; src = dst; alt = t; ns = groups;
+    }
+}
+
+template <class AffT, class XyzzT, class LF, class LFF, class LW, class LWF, class LR, class LRF>
+void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
+             MsmHornerJobs& pending, LF launch_flat, LFF launch_flat_few, LW launch_win, LWF launch_win_few, LR launch_reduce, LRF launch_reduce_few) {
+    size_t per = 0;
+    const bool fewm = n_real <= (size_t)cfg.few_max && cfg.few_path;
+    if (fewm && set.latency_flat()) {
+        // a call with a handful of statements, every part of the set as flat rows: lanes = octets of bases, the partial sums of both
+        // parts side by side, one reduction, no Horner pass
+        size_t ns = 0;
+        auto part = [&](const MsmSet<AffT>& m, bool stamp) {
+            if (!m.nflat) return;
+            const size_t nslices = ((m.nflat + 7) / 8 + 63) / 64;
+            MsmFlatRecodeArgs ra{scalars, m.frows.p, m.octwin.p, m.nflat, B, m.cv, ctx.digits, m.nbit, m.group_ok.p, ctx.gok, wires ? 1 : 0};
+            launch_msm_recode_flat_few(ra, n_real, ctx.stream);
+            MsmFlatArgs a{m.ftable.p, m.rowoff.p, m.rowlen.p, m.nflat, ctx.digits, B, nslices, 512, pa + ns * B, m.nbit, m.sub.p, ctx.gok, scalars, m.frows.p};
+            if (stamp) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
+            launch_flat_few(a, n_real, ctx.stream);
+            if (stamp) HIP_CHECK(hipEventRecord(ln.ev[6], ctx.stream));
+            ns += nslices;
+        };
+        part(set, timed);
+        if (set.few_wide) part(*set.few_wide, false);
+        if (ns) reduce_slices_few(ctx.stream, pa, pb, ns, B, B, n_real, sum, launch_reduce_few);
+        else HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ctx.stream));
+        return;
+    }
+    if (set.nflat) {
+        MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ctx.digits, set.nbit, set.group_ok.p, ctx.gok, wires ? 1 : 0};
+        if (fewm) {       // (a set whose windowed part has no latency layout: GSC_FEW_WIDE=0)
+            const size_t nslices = ((set.nflat + 7) / 8 + 63) / 64;
+            launch_msm_recode_flat_few(ra, n_real, ctx.stream);
+            MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ctx.digits, B, nslices, 512, pa, set.nbit, set.sub.p, ctx.gok, scalars, set.frows.p};
+            if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
+            launch_flat_few(a, n_real, ctx.stream);
+            if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ctx.stream));
+            reduce_slices_few(ctx.stream, pa, pb, nslices, B, B, n_real, set.nwide ? flat : sum, launch_reduce_few);
+        } else {
+            const size_t nslices = msm_slices(set.nflat, 1, 256, B, per);
+            launch_msm_recode_flat(ra, ctx.stream);
+            MsmFlatArgs a{set.ftable.p, set.rowoff.p, set.rowlen.p, set.nflat, ctx.digits, B, nslices, per, pa, set.nbit, set.sub.p, ctx.gok, scalars, set.frows.p};
+            launch_flat(a, ctx.stream);
+            reduce_slices(ctx.stream, pa, pb, nslices, B, set.nwide ? flat : sum, launch_reduce);
+        }
+    }
+    if (set.nwide) {
+        // a single Prove call (lanes = bases): slices of 512 bases — 8 gathers + 6 butterfly additions per wave, and at most 64 partial
+        // sums per column, which one reduction launch folds
+        const bool few = fewm;
+        size_t nslices = msm_slices(set.nwide, (size_t)set.nwin, WIN_SLICE, B, per);
+        if (few && nslices > (set.nwide + 511) / 512) { per = 512; nslices = (set.nwide + 511) / 512; }
+        const size_t Bw = B * (size_t)set.nwin;
+        MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ctx.digits};
+        launch_msm_recode(ra, ctx.stream);
+        MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa};
+        if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
+        if (few) launch_win_few(a, n_real, ctx.stream);
+        else launch_win(a, ctx.stream);
+        if (timed) HIP_CHECK(hipEventRecord(ln.ev[6], ctx.stream));
+        if (few) reduce_slices_few(ctx.stream, pa, pb, nslices, Bw, B, n_real, sj, launch_reduce_few);
+        else reduce_slices(ctx.stream, pa, pb, nslices, Bw, sj, launch_reduce);      // slices -> one sum per (window, proof)
+        if (pending.n >= MSM_HORNER_JOBS) throw std::runtime_error("internal: too many pending Horner passes");
+        pending.job[pending.n++] = MsmHornerJob{sj, set.nflat ? flat : (XyzzT*)nullptr, sum, set.nwin, set.c};
+    }
+    if (!set.nflat && !set.nwide) HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ctx.stream));      // empty set: the point at infinity
+}
+
+void AlgorithmImpl::run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed, bool side) {
+    const int k = set_index(set);
+    if (side) {
+        if (!set.latency_flat() || B != 64) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
+        run_msm(ln, MsmCtx{ln.side, ln.d_digits_s.p, ln.d_gok_s.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1c.p, ln.d_part1d.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, false, ln.pending1,
+                launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
+        return;
+    }
+    run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
+}
+
+void AlgorithmImpl::run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum, bool side) {
+    if (side && (!set.latency_flat() || B != 64)) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
+    run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_reduce_few_g2);
+}
+
+void AlgorithmImpl::fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
+    out.resize(rows * 32);
+    HIP_CHECK(hipMemcpy2DAsync(out.data(), 32, reinterpret_cast<const uint8_t*>(mat) + 32 * col, B * 32, 32, rows, hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipStreamSynchronize(ln.stream));
+}
+
+void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver) {
+    const size_t B = (n + 63) / 64 * 64;
+    ln.n_real = n;
+    const bool trace = cfg.trace_host;
+    const auto tc0 = std::chrono::steady_clock::now();
+    std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs, n, B, h_in, h_rs);
+    ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
+    ln.d_rs.upload(h_rs.data(), h_rs.size(), ln.stream);
+    std::vector<GlvSplit> h_glv;                                     // (lives as long as the other staging vectors of the call)
+    if (n <= (size_t)cfg.few_max && cfg.few_path && B == 64) {      // latency path: the two halves of s and r for k_fin_scalarmul_few
+        h_glv.resize(2 * n);
+        for (size_t i = 0; i < n; i++) for (int role = 0; role < 2; role++) {
+            uint32_t w[8]; memcpy(w, h_rs.data() + 64 * i + (role == 0 ? 32 : 0), 32);
+            if (!glv_split(w, h_glv[2 * i + role])) throw std::runtime_error("internal: scalar split out of range");
+        }
+        ln.d_glv.upload(h_glv.data(), h_glv.size(), ln.stream);
+    }
+    HIP_CHECK(hipMemsetAsync(ln.d_flags.p, 0, ln.d_flags.bytes(), ln.stream));
+    HIP_CHECK(hipEventRecord(ln.ev[0], ln.stream));
+    // 1. witness
+    if (cipher == CHACHA20) launch_assign_chacha(ln.d_inputs.p, ln.d_W.p, B, ln.stream);
+    else launch_assign_aes(ln.d_inputs.p, cipher == AES_128 ? 16 : 32, ln.d_W.p, B, ln.stream);
+    if (has_commitment) {
+        std::vector<uint8_t> h_mask(32 * B);
+        for (size_t i = 0; i < B; i++) memcpy(h_mask.data() + 32 * i, reqs[i < n ? i : n - 1].mask, 32);
+        ln.d_mask_in.upload(h_mask.data(), h_mask.size(), ln.stream);
+    }
+    launch_prep_rs(ln.d_rs.p, ln.d_W.p, n_wires, B, has_commitment ? ln.d_mask_in.p : nullptr, ln.d_mask.p, ln.stream);
+    HIP_CHECK(hipMemsetAsync(ln.d_status.p, 0xFF, B * 4, ln.stream));
+    SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p,
+                  has_commitment ? ln.d_mask.p : nullptr, has_commitment ? ln.d_commit.p : nullptr, has_div, 0u, nullptr};
+    DevBuf<unsigned long long> d_trace;
+    const bool strace = cfg.solver_trace;
+    if (strace) {
+        std::vector<unsigned long long> init(16 * ((size_t)n_levels + 1), 0ull);
+        if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[16 * l] = ~0ull;
+        d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
+    }
+    bool few_solver = few_solver_wanted(n, B) && allow_few_solver;
+    if (few_solver) {      // a recent give-up on this replica: skip the resident kernel for a while (see few_skip)
+        uint32_t k = few_skip.load();
+        while (k && !few_skip.compare_exchange_weak(k, k - 1)) {}
+        if (k) few_solver = false;
+    }
+    const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
+    if (few_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
+    SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
+                     ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, 1u << 21, 0u, n_levels, nullptr};
+    if (cfg.few_test_abort) { fa.poll_limit = 256; fa.test_missing = 1; }      // test: the barrier never fills
+    auto run_levels = [&](uint32_t from, uint32_t to) {
+        for (uint32_t l = from; l < to; l++) {
+            sa.first_level = l; sa.n_long = level_long[l];
+            if (level_kind[l]) {
+                if (few_solver) launch_solver_count_few(sa, few_count_ops.p, few_count_qoff.p, few_count_first[l], level_width[l], n, ln.stream);
+                else launch_solver_count_level(sa, level_width[l], ln.stream);
+            } else if (few_solver) {                   // a run of generic levels: one launch, device-wide barriers in between
+                uint32_t e = l + 1; while (e < to && !level_kind[e]) e++;
+                fa.from = l; fa.to = e; fa.trace = sa.trace;
+                HIP_CHECK(hipMemsetAsync(ln.d_fsync.p, 0, 4, ln.stream));
+                {
+                    FewSolverChain& chain = few_solver_chain(cfg.device);
+                    std::lock_guard<std::mutex> lk(chain.m);
+                    if (chain.last && chain.last != ln.ev_few) HIP_CHECK(hipStreamWaitEvent(ln.stream, chain.last, 0));
+                    // measured: 128 workgroups best for 1-2 statements, 256 (one per CU) beyond; never more than the device has CUs
+                    // (every workgroup must be resident: one per CU by construction) — the kernel works with any grid
+                    uint32_t wgs = cfg.few_workgroups ? (uint32_t)cfg.few_workgroups : (n <= 2 ? 128u : 256u);
+                    if (wgs > (uint32_t)cu_count) wgs = (uint32_t)cu_count;
+                    launch_solver_few(fa, has_div, wgs, ln.stream);
+                    HIP_CHECK(hipEventRecord(ln.ev_few, ln.stream));
+                    chain.last = ln.ev_few;
+                }
+                l = e - 1;
+            } else launch_solver_level(sa, level_width[l], ln.stream);
+        }
+    };
+    std::vector<uint8_t> h_cpts;
+    if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));      // dominant kernel of a latency-path call: the witness solver
+    if (has_commitment) {
+        // Groth16 commitment (gnark "BSB22"): solve up to the commitment hint, D = sum w_j * Basis_j over the
+        // committed wires (same MSM kernels as everything else), challenge = hash_to_field(D uncompressed) on the device, resume:
+        // nothing leaves the stream.
+        run_levels(0, commit_level);
+        run_msm_g1(ln, mPed, ln.d_W.p, 1, B, ln.d_sumD.p);
+        flush_horner_g1(ln, B, ln.stream);
+        launch_points_to_affine_be(ln.d_sumD.p, B, ln.d_cpts.p, ln.d_flags.p, 8, ln.stream);
+        launch_challenge_from_point(ln.d_cpts.p, ln.d_commit.p, B, ln.stream);
+        h_cpts.resize(128 * B);
+        run_levels(commit_level, n_levels);
+    } else run_levels(0, n_levels);
+    if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
+    if (strace) {
+        HIP_CHECK(hipStreamSynchronize(ln.stream));
+        std::vector<unsigned long long> t(16 * ((size_t)n_levels + 1));
+        HIP_CHECK(hipMemcpy(t.data(), d_trace.p, t.size() * 8, hipMemcpyDeviceToHost));
+        { const unsigned long long* w = t.data() + 16 * (size_t)n_levels; if (w[2] > w[0]) fprintf(stderr, "last launch: %.1f us, shader clock %.0f MHz\n", (double)(w[2] - w[0]) / 100.0, (double)(w[3] - w[1]) / ((double)(w[2] - w[0]) / 100.0)); }
+        fprintf(stderr, "solver trace: us after the level's first stamp (0 = not taken) | next level starts\n");
+        for (uint32_t l = 0; l < n_levels; l++) {
+            if (level_kind[l]) continue;
+            fprintf(stderr, "level %3u w %4u long %3u |", l, level_width[l], level_long[l]);
+            for (int k = 1; k < 13; k++) fprintf(stderr, " %6.2f", t[16 * l + k] ? (double)(t[16 * l + k] - t[16 * l]) / 100.0 : 0.0);
+            if (l + 1 < n_levels && !level_kind[l + 1]) fprintf(stderr, " | %6.2f", (double)(t[16 * l + 16] - t[16 * l]) / 100.0);
+            fprintf(stderr, "\n");
+        }
+    }
+    HIP_CHECK(hipEventRecord(ln.ev[1], ln.stream));
+    if (dbg) {
+        dbg->n_wires = n_wires; dbg->n_constraints = n_constraints; dbg->n = domain_n;
+        fetch_column(ln, ln.d_W.p, n_wires, B, 0, dbg->W); fetch_column(ln, ln.d_A.p, n_constraints, B, 0, dbg->A);
+        fetch_column(ln, ln.d_B.p, n_constraints, B, 0, dbg->B); fetch_column(ln, ln.d_C.p, n_constraints, B, 0, dbg->C);
+    }
+    // A latency-path call leaves the chip mostly idle, so its A and B1 sums and the two scalar multiplications that need them (s * Ar,
+    // r * Bs1: 254 serial doublings, 2 ms) start on the side stream right after the witness, beside the quotient and the other MSMs.
+    const bool early_ab = ln.n_real <= (size_t)cfg.few_max && cfg.few_path && B == 64 && mA.latency_flat() && mB1.latency_flat();
+    if (early_ab) {
+        HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
+        HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
+        run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p, false, true);
+        run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p, false, true);
+        launch_fin_scalarmul_few(ln.d_sumA.p, ln.d_sumB1.p, ln.d_glv.p, B, ln.n_real, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
+    }
+    const bool early_b2 = early_ab && mB2.latency_flat();         // the G2 sum too (it only reads the witness): a third stream
+    if (early_b2) {
+        HIP_CHECK(hipStreamWaitEvent(ln.side2, ln.ev_ab, 0));
+        run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p, true);
+        HIP_CHECK(hipEventRecord(ln.ev_s2, ln.side2));
+    }
+    // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
+    std::unique_lock<std::mutex> heavy_lock;      // held while the heavy phase is ENQUEUED: the chain's order is the enqueue order
+    HeavyChain& hchain = heavy_chain(cfg.device);
+    if (B >= HEAVY_MIN_BATCH) {
+        heavy_lock = std::unique_lock<std::mutex>(hchain.m);
+        if (hchain.last && hchain.last != ln.ev_heavy) HIP_CHECK(hipStreamWaitEvent(ln.stream, hchain.last, 0));
+    }
+    NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
+    HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
+    HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, ln.n_real <= (size_t)cfg.few_max && cfg.few_path ? ln.n_real : 0));      // latency path: the statements' columns only
+    HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
+    if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
+    // 3. MSMs.  A and B1 first: the two scalar multiplications of the assembly only need those two sums and run on a side stream
+    // beside the remaining MSMs.
+    if (!early_ab) {
+        run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p);
+        run_msm_g1(ln, mB1, ln.d_W.p, 1, B, ln.d_sumB1.p);
+        flush_horner_g1(ln, B, ln.stream);                                       // (AES-V2: the wide wires of A and B1; nothing for ChaCha20-V3)
+        HIP_CHECK(hipEventRecord(ln.ev_ab, ln.stream));
+        HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_ab, 0));
+        launch_fin_scalarmul(ln.d_sumA.p, ln.d_sumB1.p, ln.d_rs.p, B, ln.d_out.p, ln.d_flags.p, ln.d_tmp.p, ln.side);
+    }
+    if (!early_b2) run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p);
+    if (ln.pending2.n) {                                                         // the G2 Horner chain (3x a G1 one) also goes beside the MSMs
+        HIP_CHECK(hipEventRecord(ln.ev_b2, ln.stream));
+        HIP_CHECK(hipStreamWaitEvent(ln.side, ln.ev_b2, 0));
+        flush_horner_g2(ln, B, ln.side);
+    }
+    HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
+    run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
+    run_msm_g1(ln, ln.n_real <= (size_t)cfg.few_max && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
+    if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
+    flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
+    if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
+    HIP_CHECK(hipGetLastError());      // MSM launches
+    HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
+    if (heavy_lock.owns_lock()) { HIP_CHECK(hipEventRecord(ln.ev_heavy, ln.stream)); hchain.last = ln.ev_heavy; heavy_lock.unlock(); }
+    // 4. assembly
+    HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_fs, 0));
+    if (early_b2) HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_s2, 0));
+    launch_fin_combine(ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, ln.d_tmp.p, B, ln.d_out.p, ln.d_flags.p, ln.stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
+    std::vector<uint8_t> h_out(256 * B), h_flags(ln.d_flags.n); std::vector<uint32_t> h_status(B);
+    HIP_CHECK(hipMemcpyAsync(h_out.data(), ln.d_out.p, h_out.size(), hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipMemcpyAsync(h_flags.data(), ln.d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
+    if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
+    uint32_t h_fsync[2] = {0, 0};
+    if (few_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
+    const auto tc1 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipStreamSynchronize(ln.stream));
+    const auto tc2 = std::chrono::steady_clock::now();
+    if (h_fsync[1]) {      // the resident solver gave up (its workgroups never became resident together: another process's kernel on this device)
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true)) fprintf(stderr, "libprove: the resident witness kernel could not hold the device (shared with another process?); solving level by level\n");
+        const uint32_t pen = few_penalty.load();
+        few_skip.store(pen); few_penalty.store(pen < 4096 ? pen * 2 : 4096);
+        return prove_chunk(ln, reqs, n, results, dbg, false);
+    }
+    if (few_solver) few_penalty.store(16);
+    for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
+    (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
+    {
+        std::lock_guard<std::mutex> lk(stat_mu);
+        last_stat.name = latency_call ? (few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
+        last_stat.ms = ln.msm_z_kernel_ms; last_stat.statements = n; last_stat.columns = B; last_stat.nbases = mZ.nwide;
+        for (int k = 0; k < 4; k++) last_stat.stage_ms[k] = ln.stage_ms[k];
+    }
+    for (size_t i = 0; i < n; i++)
+        serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts.data() + 64 * i : nullptr, has_commitment ? h_cpts.data() + 64 * B + 64 * i : nullptr, results[i]);
+    if (trace) {
+        const auto tc3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "prove_chunk(%zu): enqueue %.2f ms, wait %.2f ms, serialise %.2f ms\n", n, ms(tc0, tc1), ms(tc1, tc2), ms(tc2, tc3));
+    }
+}
+
+void AlgorithmImpl::serialize(const uint8_t* o, uint8_t flags, uint32_t status, const uint8_t* commitment_xy, const uint8_t* pok_xy, ProofResult& res) const {
+    res.proof_len = 0; res.status = 0;
+    if (status != 0xFFFFFFFFu) { res.status = 1; return; }
+    if (flags) { res.status = 2; return; }
+    uint8_t* p = res.proof;
+    auto g1 = [&](const uint8_t* xy, uint8_t* dst) {
+        uint8_t y[32]; le_limbs_to_be(xy, dst); le_limbs_to_be(xy + 32, y);
+        dst[0] |= be_greater(y, kHalfP) ? 0xC0 : 0x80;
+    };
+    g1(o, p);
+    {   // G2: X.A1 | X.A0, flag from y (A1 unless zero, then A0)
+        uint8_t y0[32], y1[32];
+        le_limbs_to_be(o + 96, p + 32); le_limbs_to_be(o + 64, p + 64);
+        le_limbs_to_be(o + 128, y0); le_limbs_to_be(o + 160, y1);
+        const bool large = be_is_zero(y1) ? be_greater(y0, kHalfP) : be_greater(y1, kHalfP);
+        p[32] |= large ? 0xC0 : 0x80;
+    }
+    g1(o + 192, p + 96);
+    if (!commitment_xy) {
+        p[128] = p[129] = p[130] = p[131] = 0;          // no commitments (ChaCha20-V3)
+        memset(p + 132, 0, 32); p[132] = 0x40;          // CommitmentPok = point at infinity
+        res.proof_len = 164;
+    } else {                                            // one commitment + its proof of knowledge (AES-V2)
+        p[128] = p[129] = p[130] = 0; p[131] = 1;
+        auto g1be = [&](const uint8_t* xy, uint8_t* dst) { memcpy(dst, xy, 32); dst[0] |= be_greater(xy + 32, kHalfP) ? 0xC0 : 0x80; };
+        g1be(commitment_xy, p + 132); g1be(pok_xy, p + 164);
+        res.proof_len = 196;
+    }
+}
+}  // namespace gsc
