@@ -340,6 +340,7 @@ def main():
     ap.add_argument("--in-library", action="store_true", help="ONE process drives all --gpus devices through the library's own replicas (GSC_DEVICES=0..N-1): "
                                                                "what a single FFI host (Go / node) would do; one call of N x batch statements per step")
     ap.add_argument("--devices", default="", help="with --in-library: the device list itself (e.g. 0,0 rehearses two replicas on a one-GPU box)")
+    ap.add_argument("--callers", type=int, default=2, help="concurrent caller threads that keep the library busy (each owns output buffers); small batches need several in flight")
     ap.add_argument("--stub-prover", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -417,12 +418,13 @@ def main():
         inputs_of = {i: provable(xoshiro_records(BT, first_index(i)), workload) for i in ids}
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    # Two callers keep the library busy, like concurrent Prove callers do (libraries/core_test.go:44-111): while one call's batch is on the
+    # --callers threads (default two) keep the library busy, like concurrent Prove callers do (libraries/core_test.go:44-111): while one call's batch is on the
     # GPU, the other call does its host part (native cipher, CSPRNG draws, packing).  Device work of the two calls is serialised by the
     # library, so a step still means one batch through the whole path; each caller owns a set of output buffers.
     plen = 164 if workload == "chacha20" else 196
-    bufs = [g.raw_buffers(BT) if g else None for _ in range(2)]
-    free = [threading.Event() for _ in range(2)]
+    NC = max(1, args.callers)
+    bufs = [g.raw_buffers(BT) if g else None for _ in range(NC)]
+    free = [threading.Event() for _ in range(NC)]
     for e in free:
         e.set()
     stubp = StubProver(BT) if stub else None
@@ -441,7 +443,7 @@ def main():
             if out.count(b'"proofJson"') != BT:
                 raise SystemExit("rank %d: only %d of %d proofs produced" % (rank, out.count(b'"proofJson"'), BT))
             last_json[i] = out
-            last_json.pop(i - 2, None)
+            last_json.pop(i - NC, None)
             return out, [kernel_stats(n) for n in names]
         pb, lb, cb = bufs[slot]
         algo = ALGOS[workload][0]
@@ -453,8 +455,8 @@ def main():
         return pb, [kernel_stats(workload)]
 
     def run(step_ids, stats):
-        with ThreadPoolExecutor(2) as pool:
-            futs = [pool.submit(prove, i, k % 2) for k, i in enumerate(step_ids)]
+        with ThreadPoolExecutor(NC) as pool:
+            futs = [pool.submit(prove, i, k % NC) for k, i in enumerate(step_ids)]
             last = len(futs) - 1
             for k, f in enumerate(futs):          # results are consumed in order on this thread (the only one that talks to RCCL)
                 payload, st = f.result()
@@ -466,7 +468,7 @@ def main():
                 else:
                     local = torch.frombuffer(payload, dtype=torch.uint8).to(dev)
                 if k != last or stats is None:    # the last timed step's buffers stay untouched: they are verified after the clock stops
-                    free[k % 2].set()
+                    free[k % NC].set()
                 gather_proofs(dist, local, rank, world, use_dist)
                 if stats is not None:
                     stats.append(st)
@@ -509,7 +511,7 @@ def main():
                 rec = bytes(32) + base64.b64decode(q["nonce"]) + int(q["counter"]).to_bytes(4, "little") + base64.b64decode(q["input"])
                 items.append((q["cipher"], base64.b64decode(o["proof"]["proofJson"]), signals_of(cname, rec, base64.b64decode(o["publicSignals"]))))
         else:
-            pb, lb, cb = bufs[(args.steps - 1) % 2]
+            pb, lb, cb = bufs[(args.steps - 1) % NC]
             recs = inputs_of[last_id]; cipher = ALGOS[workload][1]; proofs, cts = pb.raw, cb.raw
             for k in sample_indices(BT, args.verify, edges):
                 items.append((cipher, proofs[196 * k:196 * k + plen], signals_of(workload, recs[112 * k:112 * (k + 1)], cts[64 * k:64 * k + 64])))
@@ -543,7 +545,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fr/Fp, 254-bit modular integers)",
             "data": "synthetic",
             "config": {"workload": "%s; 1xMI355X per rank: batch of %d independent proofs per GPU per step, CSPRNG (r,s); statements from xoshiro256** seeded 0x9E3779B97F4A7C15 + index" % (desc, B),
-                       "batch_per_gpu": B, "parallelism": par,
+                       "batch_per_gpu": B, "callers": NC, "parallelism": par,
                        "engine": {n: g.describe(ALGOS[n][0]) for n in names} if g else "stub"},
             "verified": verified,
         }

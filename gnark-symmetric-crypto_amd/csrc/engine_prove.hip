@@ -263,7 +263,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
     std::unique_lock<std::mutex> heavy_lock;      // held while the heavy phase is ENQUEUED: the chain's order is the enqueue order
     HeavyChain& hchain = heavy_chain(cfg.device);
-    if (B >= HEAVY_MIN_BATCH) {
+    if (B >= HEAVY_MIN_BATCH && cfg.heavy_chain) {
         heavy_lock = std::unique_lock<std::mutex>(hchain.m);
         if (hchain.last && hchain.last != ln.ev_heavy) HIP_CHECK(hipStreamWaitEvent(ln.stream, hchain.last, 0));
     }
