@@ -41,3 +41,21 @@ def test_failing_rank_fails_the_launcher():
     if torch.cuda.is_available():
         return
     assert p.returncode != 0 and not p.stdout.strip()
+
+
+def test_in_library_mode_is_one_process_for_all_devices():
+    # `bench.py --gpus N --in-library`: ONE process drives N engine replicas through GSC_DEVICES (what a single Go / node FFI host does);
+    # no rank processes, no torch.distributed; one call of N x batch statements per step; n_gpus = N in the line.  (Stub prover: the
+    # plumbing only; the real thing is rehearsed on one GPU as --devices 0,0 and kept under profiles/.)
+    out = subprocess.check_output([sys.executable, BENCH, "--gpus", "2", "--in-library", "--devices", "0,0", "--steps", "3", "--warmup", "1", "--batch", "64", "--stub-prover"],
+                                  env=_env(), timeout=300, stderr=subprocess.DEVNULL).decode()
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["batch_per_gpu"] == 64 and "in-library replicas" in line["config"]["parallelism"] and "GSC_DEVICES=0,0" in line["config"]["parallelism"]
+    assert abs(line["value"] - 2 * 3 * 64 / (line["ms_per_step"] * 3 / 1e3)) / line["value"] < 0.01
+    # the device list must match --gpus; a distributed launch of the in-library mode is refused
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--in-library", "--devices", "0", "--stub-prover"], env=_env(), capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"--devices lists 1 devices" in p.stderr
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--in-library", "--stub-prover"], env=dict(_env(), RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"), capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"one process for all GPUs" in p.stderr
