@@ -50,15 +50,6 @@ struct MsmSet {                     // one fixed-base MSM of the proving key (ke
 struct FewSolverChain { std::mutex m; hipEvent_t last = nullptr; };
 FewSolverChain& few_solver_chain(int device);      // one per device, never destroyed (lanes may outlive static destructors): engine_prove.hip
 
-// The quotient transforms and the MSMs of a big batch fill the chip on their own (VALU-bound); two of them side by side only thrash each
-// other's table gathers (measured in round 2: two lanes no faster than one).  What does overlap is the witness stage — bound by HBM
-// traffic and dependent levels, not by VALU issue — with ANOTHER batch's transforms and MSMs.  So the heavy phases of big batches are
-// chained per device, in enqueue order, with events (no host blocking), across lanes and algorithms: while one lane computes, the
-// other lane's next batch is solved.
-struct HeavyChain { std::mutex m; hipEvent_t last = nullptr; };
-HeavyChain& heavy_chain(int device);
-constexpr size_t HEAVY_MIN_BATCH = 1024;      // smaller batches leave the chip under-filled in every stage: they run freely side by side
-
 class AlgorithmImpl {
   public:
     Cipher cipher; EngineConfig cfg;
@@ -102,14 +93,14 @@ class AlgorithmImpl {
     // MSM sets
     MsmSet<G1Aff> mA, mB1, mK, mZ, mZfew, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
     // batch buffers: one set per lane.  A lane = a HIP stream with its own witness / polynomial / partial-sum buffers; with more than
-    // one lane big batches are cut into chunks that the lanes prove concurrently.  Measured on MI355X: two lanes do
-    // NOT beat one lane with the same number of proofs in flight (the MSM kernels already fill the chip and two of them thrash
-    // each other's table gathers), so the default is one lane; the option stays for hosts that prefer lower per-call latency.
+    // one full lane big batches are cut into chunks that the lanes prove concurrently.  Measured on MI355X: for FULL
+    // batches two lanes do not beat one (the MSM kernels fill the chip; chaining the heavy phases so that only the witness stage
+    // overlaps was measured in round 3: no gain either), so ChaCha20-V3 has one full lane; calls of a few dozen to a few hundred
+    // statements under-fill the chip and do gain from running side by side: the small lanes.
     struct Lane {
         hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;      // side: the assembly's scalar multiplications, beside the MSMs; side2: the B2 sum of a latency-path call
         hipEvent_t ev_ab = nullptr, ev_fs = nullptr, ev_b2 = nullptr, ev_s2 = nullptr;
         hipEvent_t ev_few = nullptr;    // completion of this lane's latest k_solver_few launch (FewSolverChain)
-        hipEvent_t ev_heavy = nullptr;  // completion of this lane's latest transforms + MSMs (HeavyChain)
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
@@ -127,8 +118,7 @@ class AlgorithmImpl {
         DevBuf<G1Xyzz> d_sj1[NSETS], d_flat1[NSETS]; DevBuf<G2Xyzz> d_sj2, d_flat2;
         MsmHornerJobs pending1{}, pending2{};
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
-        ~Lane() { if (ev_heavy) { for (int d = 0; d < 64; d++) { HeavyChain& c = heavy_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_heavy) c.last = nullptr; } (void)hipEventDestroy(ev_heavy); }
-                  if (ev_few) { for (int d = 0; d < 64; d++) { FewSolverChain& c = few_solver_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_few) c.last = nullptr; } (void)hipEventDestroy(ev_few); }
+        ~Lane() { if (ev_few) { for (int d = 0; d < 64; d++) { FewSolverChain& c = few_solver_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_few) c.last = nullptr; } (void)hipEventDestroy(ev_few); }
                   for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (ev_b2) (void)hipEventDestroy(ev_b2); if (ev_s2) (void)hipEventDestroy(ev_s2); if (side2) (void)hipStreamDestroy(side2); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;

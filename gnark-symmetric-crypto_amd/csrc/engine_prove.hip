@@ -10,7 +10,6 @@
 namespace gsc {
 
 FewSolverChain& few_solver_chain(int device) { static FewSolverChain* chains = new FewSolverChain[64]; return chains[device & 63]; }
-HeavyChain& heavy_chain(int device) { static HeavyChain* chains = new HeavyChain[64]; return chains[device & 63]; }
 
 namespace {
 // (p-1)/2, big-endian: a compressed point carries the "larger y" flag iff y > (p-1)/2
@@ -261,12 +260,6 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         HIP_CHECK(hipEventRecord(ln.ev_s2, ln.side2));
     }
     // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
-    std::unique_lock<std::mutex> heavy_lock;      // held while the heavy phase is ENQUEUED: the chain's order is the enqueue order
-    HeavyChain& hchain = heavy_chain(cfg.device);
-    if (B >= HEAVY_MIN_BATCH && cfg.heavy_chain) {
-        heavy_lock = std::unique_lock<std::mutex>(hchain.m);
-        if (hchain.last && hchain.last != ln.ev_heavy) HIP_CHECK(hipStreamWaitEvent(ln.stream, hchain.last, 0));
-    }
     NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
     HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
     HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, ln.n_real <= (size_t)cfg.few_max && cfg.few_path ? ln.n_real : 0));      // latency path: the statements' columns only
@@ -296,7 +289,6 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
     HIP_CHECK(hipGetLastError());      // MSM launches
     HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
-    if (heavy_lock.owns_lock()) { HIP_CHECK(hipEventRecord(ln.ev_heavy, ln.stream)); hchain.last = ln.ev_heavy; heavy_lock.unlock(); }
     // 4. assembly
     HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_fs, 0));
     if (early_b2) HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_s2, 0));

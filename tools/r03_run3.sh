@@ -6,6 +6,6 @@ O=gpurun_out/r03; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 show() { python -c "import json,sys;d=json.load(open(sys.argv[1]));print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], {k:round(v,1) for k,v in d['stage_ms_last_step'].items()}, d['verified'])" $1; }
 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/ref_chacha20.json 2> $O/ref_chacha20.err && show $O/ref_chacha20.json
-for c in 1 0; do GSC_HEAVY_CHAIN=$c python bench.py --workload aes128 --steps 5 --warmup 1 --no-cpu-baseline > $O/aes128_chain$c.json 2> $O/aes128_chain$c.err && show $O/aes128_chain$c.json; done
-for c in 1 0; do GSC_HEAVY_CHAIN=$c python bench.py --workload mixed --steps 4 --warmup 1 --no-cpu-baseline > $O/mixed_chain$c.json 2> $O/mixed_chain$c.err && show $O/mixed_chain$c.json; done
+
+
 for nc in 2 4; do for b in 64 128 256 512 1024; do python bench.py --batch $b --callers $nc --steps 24 --warmup 4 --no-cpu-baseline > $O/sweep_b${b}_c$nc.json 2> $O/sweep_b${b}_c$nc.err && show $O/sweep_b${b}_c$nc.json; done; done
