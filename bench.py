@@ -313,13 +313,11 @@ def roofline_of(n, rows, g):
     STATEMENTS the launch proved, not for the 64-column padding."""
     kname = rows[-1][0]; avg_ms = sum(r[1] for r in rows) / len(rows); stmts, cols, nb = rows[-1][2], rows[-1][3], rows[-1][4]
     solver = kname.startswith("k_solver")
-    graph = kname.startswith("pipeline")            # a mid-size call replayed as ONE hipGraph: the whole pipeline is the timed unit
-    alg_bytes = stmts * (WITNESS_BYTES_PER_PROOF[n] if solver else BYTES_PER_PROOF[n] if graph else nb * MSM_Z_BYTES_PER_BASE)
+    alg_bytes = stmts * (WITNESS_BYTES_PER_PROOF[n] if solver else nb * MSM_Z_BYTES_PER_BASE)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     msm_ms = sum(r[5]["msm"] for r in rows) / len(rows)
-    traffic, src = (None, None) if (solver or graph) else pmc_traffic(n, cols, g.describe(ALGOS[n][0]))
-    what = "resident witness solver of the latency path" if solver else "every kernel of one call, SURVEY 8(d) whole-path bytes" if graph else "Z-table gather-accumulate"
-    return {"kernel": "%s (%s, %s)" % (kname, what, n), "bound": "hbm",
+    traffic, src = (None, None) if solver else pmc_traffic(n, cols, g.describe(ALGOS[n][0]))
+    return {"kernel": "%s (%s, %s)" % (kname, "resident witness solver of the latency path" if solver else "Z-table gather-accumulate", n), "bound": "hbm",
             "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic, "traffic_source": src, "launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
             "proofs_per_launch": stmts, "columns_per_launch": cols,

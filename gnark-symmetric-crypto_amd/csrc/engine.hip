@@ -44,7 +44,6 @@ EngineConfig config_from_env() {
     c.few_z_gb = env_int("GSC_FEW_Z_GB", 12);
     c.few_wide = env_int("GSC_FEW_WIDE", 1);
     if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");
-    c.graphs = env_int("GSC_GRAPHS", 1);
     c.trace_host = getenv("GSC_TRACE_HOST") != nullptr;
     if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; }
     if (c.max_batch < 64) c.max_batch = 64;

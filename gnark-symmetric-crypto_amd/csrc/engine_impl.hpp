@@ -8,7 +8,6 @@
 #include "kernels.hpp"
 #include <atomic>
 #include <condition_variable>
-#include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -29,15 +28,6 @@ struct DevBuf {
     void alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; if (count) HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T))); }
     void upload(const T* src, size_t count, hipStream_t s) { HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s)); }
     size_t bytes() const { return n * sizeof(T); }
-};
-
-template <class T>
-struct HostBuf {      // pinned host memory
-    T* p = nullptr; size_t n = 0;
-    HostBuf() = default;
-    HostBuf(const HostBuf&) = delete; HostBuf& operator=(const HostBuf&) = delete;
-    ~HostBuf() { if (p) (void)hipHostFree(p); }
-    void alloc(size_t count) { if (p) { (void)hipHostFree(p); p = nullptr; } n = count; if (count) HIP_CHECK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault)); }
 };
 
 template <class AffT>
@@ -115,10 +105,6 @@ class AlgorithmImpl {
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
         size_t cap = 0;
-        // host staging: pinned, fixed addresses (inputs, randomness, commitment masks in; points, flags, solver status, commitment points out)
-        HostBuf<uint8_t> h_in, h_rs, h_mask, h_out, h_flags, h_cpts; HostBuf<uint32_t> h_status, h_fsync;
-        // calls of up to GRAPH_MAX_BATCH statements on the batch path: their launch sequence, captured once per batch size, replayed with one launch
-        std::map<size_t, hipGraphExec_t> graphs;
         DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync; DevBuf<GlvSplit> d_glv;
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
@@ -132,22 +118,20 @@ class AlgorithmImpl {
         DevBuf<G1Xyzz> d_sj1[NSETS], d_flat1[NSETS]; DevBuf<G2Xyzz> d_sj2, d_flat2;
         MsmHornerJobs pending1{}, pending2{};
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
-        ~Lane() { for (auto& g : graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
-                  if (ev_few) { for (int d = 0; d < 64; d++) { FewSolverChain& c = few_solver_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_few) c.last = nullptr; } (void)hipEventDestroy(ev_few); }
+        ~Lane() { if (ev_few) { for (int d = 0; d < 64; d++) { FewSolverChain& c = few_solver_chain(d); std::lock_guard<std::mutex> lk(c.m); if (c.last == ev_few) c.last = nullptr; } (void)hipEventDestroy(ev_few); }
                   for (auto& e : ev) if (e) (void)hipEventDestroy(e); if (ev_ab) (void)hipEventDestroy(ev_ab); if (ev_fs) (void)hipEventDestroy(ev_fs); if (ev_b2) (void)hipEventDestroy(ev_b2); if (ev_s2) (void)hipEventDestroy(ev_s2); if (side2) (void)hipStreamDestroy(side2); if (side) (void)hipStreamDestroy(side); if (stream) (void)hipStreamDestroy(stream); }
     };
     std::vector<std::unique_ptr<Lane>> lanes;
     size_t cap = 0;                     // proofs per full lane = the largest chunk
     size_t full_lanes = 0;              // lanes [0, full_lanes) hold `cap` proofs; the rest are small lanes (SMALL_LANE_CAP)
     static constexpr size_t SMALL_LANE_CAP = 512;
-    static constexpr size_t GRAPH_MAX_BATCH = 512;      // calls up to this many columns replay a captured hipGraph (engine_prove.hip prove_chunk)
 
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf);
     ~AlgorithmImpl() { lanes.clear(); if (stream) (void)hipStreamDestroy(stream); }
 
     void init_program(const R1csFile& cs);
 
-    static void pack_inputs(const ProofRequest* reqs, size_t n, size_t B, uint8_t* h_in, uint8_t* h_rs);      // 176 B and 64 B per column
+    static void pack_inputs(const ProofRequest* reqs, size_t n, size_t B, std::vector<uint8_t>& h_in, std::vector<uint8_t>& h_rs);
 
     // Which wires are bits?  Nothing in an R1CS says so, but it is a property of the circuit, not of the statement: solve 64
     // pseudo-random statements once and call a wire a bit when it is 0 or 1 in all of them.  This is only a PREDICTION used to

@@ -138,18 +138,38 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     ln.n_real = n;
     const bool trace = cfg.trace_host;
     const auto tc0 = std::chrono::steady_clock::now();
-    // host staging lives in the lane's pinned buffers: fixed addresses (a captured graph replays its copies from / to them) and truly
-    // asynchronous copies
-    pack_inputs(reqs, n, B, ln.h_in.p, ln.h_rs.p);
-    if (has_commitment) for (size_t i = 0; i < B; i++) memcpy(ln.h_mask.p + 32 * i, reqs[i < n ? i : n - 1].mask, 32);
-    std::vector<GlvSplit> h_glv;                                     // (lives as long as the call)
-    const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
-    if (latency_call) {      // the two halves of s and r for k_fin_scalarmul_few
+    std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs, n, B, h_in, h_rs);
+    ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
+    ln.d_rs.upload(h_rs.data(), h_rs.size(), ln.stream);
+    std::vector<GlvSplit> h_glv;                                     // (lives as long as the other staging vectors of the call)
+    if (n <= (size_t)cfg.few_max && cfg.few_path && B == 64) {      // latency path: the two halves of s and r for k_fin_scalarmul_few
         h_glv.resize(2 * n);
         for (size_t i = 0; i < n; i++) for (int role = 0; role < 2; role++) {
-            uint32_t w[8]; memcpy(w, ln.h_rs.p + 64 * i + (role == 0 ? 32 : 0), 32);
+            uint32_t w[8]; memcpy(w, h_rs.data() + 64 * i + (role == 0 ? 32 : 0), 32);
             if (!glv_split(w, h_glv[2 * i + role])) throw std::runtime_error("internal: scalar split out of range");
         }
+        ln.d_glv.upload(h_glv.data(), h_glv.size(), ln.stream);
+    }
+    HIP_CHECK(hipMemsetAsync(ln.d_flags.p, 0, ln.d_flags.bytes(), ln.stream));
+    HIP_CHECK(hipEventRecord(ln.ev[0], ln.stream));
+    // 1. witness
+    if (cipher == CHACHA20) launch_assign_chacha(ln.d_inputs.p, ln.d_W.p, B, ln.stream);
+    else launch_assign_aes(ln.d_inputs.p, cipher == AES_128 ? 16 : 32, ln.d_W.p, B, ln.stream);
+    if (has_commitment) {
+        std::vector<uint8_t> h_mask(32 * B);
+        for (size_t i = 0; i < B; i++) memcpy(h_mask.data() + 32 * i, reqs[i < n ? i : n - 1].mask, 32);
+        ln.d_mask_in.upload(h_mask.data(), h_mask.size(), ln.stream);
+    }
+    launch_prep_rs(ln.d_rs.p, ln.d_W.p, n_wires, B, has_commitment ? ln.d_mask_in.p : nullptr, ln.d_mask.p, ln.stream);
+    HIP_CHECK(hipMemsetAsync(ln.d_status.p, 0xFF, B * 4, ln.stream));
+    SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p,
+                  has_commitment ? ln.d_mask.p : nullptr, has_commitment ? ln.d_commit.p : nullptr, has_div, 0u, nullptr};
+    DevBuf<unsigned long long> d_trace;
+    const bool strace = cfg.solver_trace;
+    if (strace) {
+        std::vector<unsigned long long> init(16 * ((size_t)n_levels + 1), 0ull);
+        if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[16 * l] = ~0ull;
+        d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
     }
     bool few_solver = few_solver_wanted(n, B) && allow_few_solver;
     if (few_solver) {      // a recent give-up on this replica: skip the resident kernel for a while (see few_skip)
@@ -157,33 +177,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         while (k && !few_skip.compare_exchange_weak(k, k - 1)) {}
         if (k) few_solver = false;
     }
-    const bool strace = cfg.solver_trace;
-    // Mid-size calls (a few dozen to a few hundred statements) are ~700 small dependent launches: with several of them in flight the
-    // process is bound by the HIP launch path its caller threads share (measured: three processes with two callers each prove 9.4 k
-    // statements/s at 64 per call, one process with six callers 6.2 k).  Their launch sequence depends on (lane, B) only, so it is
-    // captured ONCE into a hipGraph and replayed with a single launch.  Not for latency-path calls (their kernels depend on n), debug
-    // or trace runs; big batches are device-bound and keep their per-stage events.
-    const bool use_graph = cfg.graphs && !latency_call && !dbg && !strace && B <= GRAPH_MAX_BATCH;
-    DevBuf<unsigned long long> d_trace;
-    auto enqueue = [&](bool stage_events) {
-    ln.d_inputs.upload(ln.h_in.p, 176 * B, ln.stream);
-    ln.d_rs.upload(ln.h_rs.p, 64 * B, ln.stream);
-    if (latency_call) ln.d_glv.upload(h_glv.data(), h_glv.size(), ln.stream);
-    HIP_CHECK(hipMemsetAsync(ln.d_flags.p, 0, ln.d_flags.bytes(), ln.stream));
-    if (stage_events) HIP_CHECK(hipEventRecord(ln.ev[0], ln.stream));
-    // 1. witness
-    if (cipher == CHACHA20) launch_assign_chacha(ln.d_inputs.p, ln.d_W.p, B, ln.stream);
-    else launch_assign_aes(ln.d_inputs.p, cipher == AES_128 ? 16 : 32, ln.d_W.p, B, ln.stream);
-    if (has_commitment) ln.d_mask_in.upload(ln.h_mask.p, 32 * B, ln.stream);
-    launch_prep_rs(ln.d_rs.p, ln.d_W.p, n_wires, B, has_commitment ? ln.d_mask_in.p : nullptr, ln.d_mask.p, ln.stream);
-    HIP_CHECK(hipMemsetAsync(ln.d_status.p, 0xFF, B * 4, ln.stream));
-    SolverArgs sa{prog.p, sched.p, 0, n_levels, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p,
-                  has_commitment ? ln.d_mask.p : nullptr, has_commitment ? ln.d_commit.p : nullptr, has_div, 0u, nullptr};
-    if (strace) {
-        std::vector<unsigned long long> init(16 * ((size_t)n_levels + 1), 0ull);
-        if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[16 * l] = ~0ull;
-        d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
-    }
+    const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
     if (few_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
     SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
                      ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, 1u << 21, 0u, n_levels, nullptr};
@@ -214,6 +208,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
             } else launch_solver_level(sa, level_width[l], ln.stream);
         }
     };
+    std::vector<uint8_t> h_cpts;
     if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));      // dominant kernel of a latency-path call: the witness solver
     if (has_commitment) {
         // Groth16 commitment (gnark "BSB22"): solve up to the commitment hint, D = sum w_j * Basis_j over the
@@ -224,6 +219,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         flush_horner_g1(ln, B, ln.stream);
         launch_points_to_affine_be(ln.d_sumD.p, B, ln.d_cpts.p, ln.d_flags.p, 8, ln.stream);
         launch_challenge_from_point(ln.d_cpts.p, ln.d_commit.p, B, ln.stream);
+        h_cpts.resize(128 * B);
         run_levels(commit_level, n_levels);
     } else run_levels(0, n_levels);
     if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
@@ -241,7 +237,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
             fprintf(stderr, "\n");
         }
     }
-    if (stage_events) HIP_CHECK(hipEventRecord(ln.ev[1], ln.stream));
+    HIP_CHECK(hipEventRecord(ln.ev[1], ln.stream));
     if (dbg) {
         dbg->n_wires = n_wires; dbg->n_constraints = n_constraints; dbg->n = domain_n;
         fetch_column(ln, ln.d_W.p, n_wires, B, 0, dbg->W); fetch_column(ln, ln.d_A.p, n_constraints, B, 0, dbg->A);
@@ -267,7 +263,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
     HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
     HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, ln.n_real <= (size_t)cfg.few_max && cfg.few_path ? ln.n_real : 0));      // latency path: the statements' columns only
-    if (stage_events) HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
+    HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
     if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
     // 3. MSMs.  A and B1 first: the two scalar multiplications of the assembly only need those two sums and run on a side stream
     // beside the remaining MSMs.
@@ -287,47 +283,28 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     }
     HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
     run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
-    run_msm_g1(ln, ln.n_real <= (size_t)cfg.few_max && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call && stage_events);
+    run_msm_g1(ln, ln.n_real <= (size_t)cfg.few_max && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
     if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
     flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
     if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
     HIP_CHECK(hipGetLastError());      // MSM launches
-    if (stage_events) HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
+    HIP_CHECK(hipEventRecord(ln.ev[3], ln.stream));
     // 4. assembly
     HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_fs, 0));
     if (early_b2) HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_s2, 0));
     launch_fin_combine(ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, ln.d_tmp.p, B, ln.d_out.p, ln.d_flags.p, ln.stream);
     HIP_CHECK(hipGetLastError());
-    if (stage_events) HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
-    HIP_CHECK(hipMemcpyAsync(ln.h_out.p, ln.d_out.p, 256 * B, hipMemcpyDeviceToHost, ln.stream));
-    HIP_CHECK(hipMemcpyAsync(ln.h_flags.p, ln.d_flags.p, ln.d_flags.n, hipMemcpyDeviceToHost, ln.stream));
-    HIP_CHECK(hipMemcpyAsync(ln.h_status.p, ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
-    if (has_commitment) HIP_CHECK(hipMemcpyAsync(ln.h_cpts.p, ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
-    if (few_solver) HIP_CHECK(hipMemcpyAsync(ln.h_fsync.p, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
-    };      // enqueue
-    ln.h_fsync.p[0] = ln.h_fsync.p[1] = 0;
-    if (!use_graph) enqueue(true);
-    else {
-        hipGraphExec_t& exec = ln.graphs[B];
-        if (!exec) {      // first call of this size on this lane: capture the launch sequence (nothing executes), instantiate
-            hipGraph_t graph = nullptr;
-            HIP_CHECK(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
-            try { enqueue(false); }
-            catch (...) { (void)hipStreamEndCapture(ln.stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
-            HIP_CHECK(hipStreamEndCapture(ln.stream, &graph));
-            const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess) { exec = nullptr; throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(ie) + " at hipGraphInstantiate"); }
-        }
-        HIP_CHECK(hipEventRecord(ln.ev[0], ln.stream));
-        HIP_CHECK(hipGraphLaunch(exec, ln.stream));
-        HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
-    }
+    HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
+    std::vector<uint8_t> h_out(256 * B), h_flags(ln.d_flags.n); std::vector<uint32_t> h_status(B);
+    HIP_CHECK(hipMemcpyAsync(h_out.data(), ln.d_out.p, h_out.size(), hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipMemcpyAsync(h_flags.data(), ln.d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
+    if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
+    uint32_t h_fsync[2] = {0, 0};
+    if (few_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
     const auto tc1 = std::chrono::steady_clock::now();
     HIP_CHECK(hipStreamSynchronize(ln.stream));
     const auto tc2 = std::chrono::steady_clock::now();
-    const uint32_t* h_fsync = ln.h_fsync.p;
-    const uint8_t* h_out = ln.h_out.p; const uint8_t* h_flags = ln.h_flags.p; const uint32_t* h_status = ln.h_status.p; const uint8_t* h_cpts = ln.h_cpts.p;
     if (h_fsync[1]) {      // the resident solver gave up (its workgroups never became resident together: another process's kernel on this device)
         static std::atomic<bool> warned{false};
         if (!warned.exchange(true)) fprintf(stderr, "libprove: the resident witness kernel could not hold the device (shared with another process?); solving level by level\n");
@@ -336,23 +313,16 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         return prove_chunk(ln, reqs, n, results, dbg, false);
     }
     if (few_solver) few_penalty.store(16);
-    if (use_graph) {      // one replayed graph: the device time of the whole pipeline is all there is to report
-        float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[0], ln.ev[4]);
-        ln.stage_ms[0] = ln.stage_ms[1] = ln.stage_ms[3] = 0; ln.stage_ms[2] = ms; ln.msm_z_kernel_ms = ms;
-    } else {
-        for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
-        (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]);
-    }
-    ln.last_batch = B;
+    for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
+    (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
     {
         std::lock_guard<std::mutex> lk(stat_mu);
-        last_stat.name = use_graph ? "pipeline (hipGraph replay: witness + quotient + MSMs + assembly)"
-                       : latency_call ? (few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
+        last_stat.name = latency_call ? (few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
         last_stat.ms = ln.msm_z_kernel_ms; last_stat.statements = n; last_stat.columns = B; last_stat.nbases = mZ.nwide;
         for (int k = 0; k < 4; k++) last_stat.stage_ms[k] = ln.stage_ms[k];
     }
     for (size_t i = 0; i < n; i++)
-        serialize(h_out + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts + 64 * i : nullptr, has_commitment ? h_cpts + 64 * B + 64 * i : nullptr, results[i]);
+        serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts.data() + 64 * i : nullptr, has_commitment ? h_cpts.data() + 64 * B + 64 * i : nullptr, results[i]);
     if (trace) {
         const auto tc3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

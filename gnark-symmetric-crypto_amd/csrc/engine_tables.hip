@@ -99,16 +99,16 @@ void AlgorithmImpl::init_program(const R1csFile& cs) {
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
-void AlgorithmImpl::pack_inputs(const ProofRequest* reqs, size_t n, size_t B, uint8_t* h_in, uint8_t* h_rs) {
-    memset(h_in, 0, 176 * B); memset(h_rs, 0, 64 * B);
+void AlgorithmImpl::pack_inputs(const ProofRequest* reqs, size_t n, size_t B, std::vector<uint8_t>& h_in, std::vector<uint8_t>& h_rs) {
+    h_in.assign(176 * B, 0); h_rs.assign(64 * B, 0);
     for (size_t i = 0; i < B; i++) {
         const ProofRequest& q = reqs[i < n ? i : n - 1];
-        uint8_t* rec = h_in + 176 * i;
+        uint8_t* rec = h_in.data() + 176 * i;
         memcpy(rec, q.key, q.keylen);
         memcpy(rec + 32, q.nonce, 12);
         rec[44] = (uint8_t)q.counter; rec[45] = (uint8_t)(q.counter >> 8); rec[46] = (uint8_t)(q.counter >> 16); rec[47] = (uint8_t)(q.counter >> 24);
         memcpy(rec + 48, q.plaintext, 64); memcpy(rec + 112, q.ciphertext, 64);
-        memcpy(h_rs + 64 * i, q.r, 32); memcpy(h_rs + 64 * i + 32, q.s, 32);
+        memcpy(h_rs.data() + 64 * i, q.r, 32); memcpy(h_rs.data() + 64 * i + 32, q.s, 32);
     }
 }
 
@@ -132,7 +132,7 @@ void AlgorithmImpl::calibrate() {
         else aes_ctr_xor_stream(q.key, q.keylen, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
         q.r[0] = 3; q.s[0] = 5; q.mask[0] = 7;
     }
-    std::vector<uint8_t> h_in(176 * B), h_rs(64 * B); pack_inputs(reqs.data(), B, B, h_in.data(), h_rs.data());
+    std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs.data(), B, B, h_in, h_rs);
     DevBuf<uint8_t> d_inputs(h_in.size()), d_rs(h_rs.size()), d_mask_in(32 * B); DevBuf<uint32_t> d_status(B);
     DevBuf<fe> d_W((n_wires + 4) * B), d_A(n_constraints * B), d_B(n_constraints * B), d_C(n_constraints * B), d_mask(B), d_commit(B);
     d_inputs.upload(h_in.data(), h_in.size(), stream); d_rs.upload(h_rs.data(), h_rs.size(), stream);
@@ -373,8 +373,6 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
-    ln.h_in.alloc(176 * B); ln.h_rs.alloc(64 * B); ln.h_mask.alloc(has_commitment ? 32 * B : 1); ln.h_out.alloc(256 * B); ln.h_flags.alloc((B + 3) / 4 * 4); ln.h_status.alloc(B);
-    ln.h_cpts.alloc(has_commitment ? 128 * B : 1); ln.h_fsync.alloc(2);
     ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2); ln.d_glv.alloc(2 * MSM_FEW_PROOFS);
     ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
     // calls with a handful of statements (k_solver_few) write their own columns only: the others must always hold field elements
