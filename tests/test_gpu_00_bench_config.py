@@ -80,16 +80,26 @@ def test_the_timed_configuration_proves_8192_statements_bit_exactly(gsc, oracle,
     assert len({proofs[196 * k:196 * k + 164] for k in range(n)}) == n
 
 
-def test_bench_verifies_its_own_proofs_and_reports_it(tmp_path):
+def _bench_line(*args):
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + list(args), env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_verifies_its_own_proofs_and_reports_it():
     # bench.py itself, small (a batch of 256 at the session's table budget): the JSON line must carry "verified" and the roofline
     # bookkeeping of the launch it timed; a run whose proofs do not verify exits non-zero (bench.py: "REJECTED").
-    import json
-    env = dict(os.environ)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "256", "--verify", "64", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    line = _bench_line("--steps", "2", "--warmup", "1", "--batch", "256", "--verify", "64")
     assert line["verified"] == 64 and line["n_gpus"] == 1 and line["config"]["batch_per_gpu"] == 256
     rf = line["roofline"]
     assert rf["proofs_per_launch"] == 256 and rf["kernel"].startswith("k_msm_win") and rf["algorithmic_bytes_per_launch"] == 256 * 32767 * 96
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and "traffic_source" in rf
+
+
+def test_bench_bookkeeping_of_a_single_statement_call():
+    # bytes are counted for the STATEMENTS a launch proved and for the kernel that was timed.  One statement per call:
+    # the resident witness kernel of the latency path, SURVEY 8(d)'s witness bytes of ONE proof (not of 64 padded columns).
+    one = _bench_line("--steps", "6", "--warmup", "2", "--batch", "1", "--verify", "1")["roofline"]
+    assert one["kernel"].startswith("k_solver_few") and one["proofs_per_launch"] == 1 and one["columns_per_launch"] == 64
+    assert one["algorithmic_bytes_per_launch"] == 3012224 and one["traffic"] is None
