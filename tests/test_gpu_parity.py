@@ -229,7 +229,7 @@ def test_engine_options_do_not_change_the_proofs():
     # GSC_DEVICES=0,0: two engine replicas (here both on the one device of the box), every batch split between them — the in-library
     # multi-GPU path of a single FFI host process.
     for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_DEVICES": "0,0"}, {"GSC_WINDOW_Z": "11", "GSC_MIN_SPLIT": "512"},
-                  {"GSC_WINDOW_Z": "0", "GSC_Z_TABLE_GB": "1", "GSC_LINGER_US": "0"}):
+                  {"GSC_WINDOW_Z": "0", "GSC_Z_TABLE_GB": "1", "GSC_LINGER_US": "0"}, {"GSC_SMALL_LANES": "0"}):
         assert _digest(extra) == base, extra
 
 
