@@ -40,8 +40,6 @@ EngineConfig config_from_env() {
     c.few_solver = env_int("GSC_FEW_SOLVER", 1);
     c.few_max = env_int("GSC_FEW_MAX", 0);
     if (c.few_max < 0 || c.few_max > (int)MSM_FEW_PROOFS) throw std::runtime_error("GSC_FEW_MAX must be in [0, 32]");
-    c.res_solver = env_int("GSC_RES_SOLVER", 1);
-    c.res_solver_max = (size_t)env_int("GSC_RES_SOLVER_MAX", 2048);
     c.few_workgroups = env_int("GSC_FEW_WGS", 0);
     c.few_z_gb = env_int("GSC_FEW_Z_GB", 12);
     c.few_wide = env_int("GSC_FEW_WIDE", 1);

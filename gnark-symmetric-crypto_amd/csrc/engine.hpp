@@ -43,9 +43,6 @@ struct EngineConfig {
     int few_path = 1;            // GSC_FEW_PATH: calls with at most few_max statements use the latency kernels for the MSMs, the quotient and the assembly; 0 = always the batch kernels
     int few_max = 0;             // GSC_FEW_MAX: the largest call the latency kernels take (<= MSM_FEW_PROOFS = 32); 0 = 32 for ChaCha20 (4.6 ms for 1 statement, 7.8 ms for 16, 11.3 ms for 32; the batch kernels need 12.3 ms for anything up to 64), 20 for AES (8.2 ms for 1, +1.6 ms each: 38.4 ms for 20; batch kernels 43.7 ms)
     int few_solver = 1;          // GSC_FEW_SOLVER: such calls also solve the witness with the resident lanes-are-terms kernel (k_solver_few); 0 = one launch per level
-    int res_solver = 1;          // GSC_RES_SOLVER: batch-path calls of up to res_solver_max columns solve the witness with the resident lanes-are-proofs kernel
-                                 // (k_solver_res: one launch per run of levels, device-wide barriers); 0 = one launch per level
-    size_t res_solver_max = 2048; // GSC_RES_SOLVER_MAX: the largest batch (columns) that takes it; bigger batches are bound by HBM traffic, not by launches
     int few_workgroups = 0;      // GSC_FEW_WGS: its grid (workgroups of 8 waves, one per CU, so all are resident); 0 = 128 for 1-2 statements, 256 beyond
     int few_z_gb = 12;           // GSC_FEW_Z_GB: HBM budget of the latency-path layout of the quotient bases (rows per (base, window) of 8-, 6- or 4-bit digits: 8.6 GB ChaCha20 at 8, 11.5 GB AES at 6); 0 = none, such calls run the Horner pass
     int few_wide = 1;            // GSC_FEW_WIDE: the wide wires of the wire sets (AES: ~6 k per set) also get (base, window) rows for the latency path (~7.5 GB per AES algorithm); 0 = such calls run the windowed kernel + Horner for them

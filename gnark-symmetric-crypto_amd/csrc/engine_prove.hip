@@ -171,17 +171,14 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[16 * l] = ~0ull;
         d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
     }
-    const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
-    // Resident witness kernels (one launch per run of levels, device-wide barriers): lanes = terms for latency-path calls (k_solver_few),
-    // lanes = proofs for batches of moderate size (k_solver_res); bigger batches are bound by HBM traffic, not by launches.
     bool few_solver = few_solver_wanted(n, B) && allow_few_solver;
-    bool res_solver = !latency_call && allow_few_solver && cfg.res_solver && B <= cfg.res_solver_max && !strace;
-    if (few_solver || res_solver) {      // a recent give-up on this replica: skip the resident kernels for a while (see few_skip)
+    if (few_solver) {      // a recent give-up on this replica: skip the resident kernel for a while (see few_skip)
         uint32_t k = few_skip.load();
         while (k && !few_skip.compare_exchange_weak(k, k - 1)) {}
-        if (k) few_solver = res_solver = false;
+        if (k) few_solver = false;
     }
-    if (few_solver || res_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
+    const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
+    if (few_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
     SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
                      ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, 1u << 21, 0u, n_levels, nullptr};
     if (cfg.few_test_abort) { fa.poll_limit = 256; fa.test_missing = 1; }      // test: the barrier never fills
@@ -204,20 +201,6 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
                     uint32_t wgs = cfg.few_workgroups ? (uint32_t)cfg.few_workgroups : (n <= 2 ? 128u : 256u);
                     if (wgs > (uint32_t)cu_count) wgs = (uint32_t)cu_count;
                     launch_solver_few(fa, has_div, wgs, ln.stream);
-                    HIP_CHECK(hipEventRecord(ln.ev_few, ln.stream));
-                    chain.last = ln.ev_few;
-                }
-                l = e - 1;
-            } else if (res_solver) {                   // the same for a batch: lanes = proofs, one resident launch per run of generic levels
-                uint32_t e = l + 1; while (e < to && !level_kind[e]) e++;
-                SolverResArgs ra{sa, l, e, d_level_long.p, ln.d_fsync.p, 1u << 21, 0u};
-                if (cfg.few_test_abort) { ra.poll_limit = 256; ra.test_missing = 1; }
-                HIP_CHECK(hipMemsetAsync(ln.d_fsync.p, 0, 4, ln.stream));
-                {
-                    FewSolverChain& chain = few_solver_chain(cfg.device);      // resident kernels never share the device, whatever their kind
-                    std::lock_guard<std::mutex> lk(chain.m);
-                    if (chain.last && chain.last != ln.ev_few) HIP_CHECK(hipStreamWaitEvent(ln.stream, chain.last, 0));
-                    launch_solver_resident(ra, (uint32_t)(cu_count < 256 ? cu_count : 256), ln.stream);
                     HIP_CHECK(hipEventRecord(ln.ev_few, ln.stream));
                     chain.last = ln.ev_few;
                 }
@@ -318,7 +301,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
     if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
     uint32_t h_fsync[2] = {0, 0};
-    if (few_solver || res_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
+    if (few_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
     const auto tc1 = std::chrono::steady_clock::now();
     HIP_CHECK(hipStreamSynchronize(ln.stream));
     const auto tc2 = std::chrono::steady_clock::now();
@@ -329,7 +312,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         few_skip.store(pen); few_penalty.store(pen < 4096 ? pen * 2 : 4096);
         return prove_chunk(ln, reqs, n, results, dbg, false);
     }
-    if (few_solver || res_solver) few_penalty.store(16);
+    if (few_solver) few_penalty.store(16);
     for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
     (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
     {

@@ -71,8 +71,6 @@ void AlgorithmImpl::init_program(const R1csFile& cs) {
     n_levels = (uint32_t)sp.n_levels; commit_level = (uint32_t)sp.commit_level; has_div = sp.n_inversions ? 1 : 0;
     level_width.resize(n_levels); for (uint32_t l = 0; l < n_levels; l++) level_width[l] = sp.sched[2 + l] - sp.sched[1 + l];
     level_kind = sp.level_kind; level_long = sp.level_long;
-    d_level_long.alloc(level_long.size() ? level_long.size() : 1);
-    if (!level_long.empty()) d_level_long.upload(level_long.data(), level_long.size(), stream);
     prog.alloc(sp.words.size()); prog.upload(sp.words.data(), sp.words.size(), stream);
     sched.alloc(sp.sched.size()); sched.upload(sp.sched.data(), sp.sched.size(), stream);
     {

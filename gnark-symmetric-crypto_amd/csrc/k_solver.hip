@@ -117,19 +117,26 @@ __device__ __forceinline__ fe eval_expr(Window& win, uint32_t at, const fe* coef
 // chip-wide); grid = (proof groups of 64, ops in the level); one op per workgroup.  The WPB waves of the workgroup split
 // the chunks of the op's linear expressions (ChaCha's add32 rows have 130 terms and would otherwise be one wave's serial
 // work — a lone wave issues an instruction only every ~9 cycles) and combine the partial sums through LDS.
-// One op `i` of level `lev` for the 64 proofs p - lane .. p - lane + 63.  coop (uniform over the workgroup): the op's terms are split
-// over the WPB waves, which combine their partial sums through LDS (one __syncthreads inside: every wave of the workgroup must make the
-// call); otherwise the calling wave works alone in its own LDS slot.  Shared by the one-launch-per-level kernel and the resident one.
 template <bool HAS_DIV, int WPB>
-__device__ __forceinline__ void solver_item(const SolverArgs& a, uint32_t lev, uint32_t i, size_t p, bool coop, uint32_t wave, uint32_t lane, uint32_t (*s_part)[WPB][8][64]) {
+__global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
+    __shared__ uint32_t s_part[3][WPB][8][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t p = (size_t)blockIdx.x * 64 + lane;
     const size_t batch = a.batch;
     const uint32_t nlev = a.sched[0];
+    const uint32_t* lstart = a.sched + 1;
     const uint32_t* ops = a.sched + 2 + nlev;
+    const uint32_t lev = a.first_level;
     auto stamp = [&](int k) {
         if (a.trace && lane == 0) { const unsigned long long t = wall_clock64(); if (k == 0) atomicMin(a.trace + 16 * lev, t); else atomicMax(a.trace + 16 * lev + k, t); }
     };
     stamp(0);
+    // workgroups [0, n_long): one long op each, its terms split over the WPB waves;
+    // workgroups [n_long, ...): WPB short ops each, one per wave (the LDS exchange then has a single contributor)
+    const bool coop = blockIdx.y < a.n_long;
+    const uint32_t i = lstart[lev] + (coop ? blockIdx.y : a.n_long + (blockIdx.y - a.n_long) * WPB + wave);
     const uint32_t part = coop ? wave : 0u, nparts = coop ? (uint32_t)WPB : 1u, slot = coop ? 0u : wave;
+    if (i >= lstart[lev + 1]) return;          // only in wave-per-op workgroups, which never reach a barrier
     bool bad = false;
     Window win{a.prog, 0, 0, lane};
     const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)ops[i]);
@@ -235,20 +242,6 @@ __device__ __forceinline__ void solver_item(const SolverArgs& a, uint32_t lev, u
     }
     if (bad) atomicMin(a.status + p, i);     // status: 0xFFFFFFFF = satisfied, else first failing op
     stamp(5);
-}
-
-template <bool HAS_DIV, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
-    __shared__ uint32_t s_part[3][WPB][8][64];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t* lstart = a.sched + 1;
-    const uint32_t lev = a.first_level;
-    // workgroups [0, n_long): one long op each, its terms split over the WPB waves;
-    // workgroups [n_long, ...): WPB short ops each, one per wave (the LDS exchange then has a single contributor)
-    const bool coop = blockIdx.y < a.n_long;
-    const uint32_t i = lstart[lev] + (coop ? blockIdx.y : a.n_long + (blockIdx.y - a.n_long) * WPB + wave);
-    if (i >= lstart[lev + 1]) return;          // only in wave-per-op workgroups, which never reach a barrier
-    solver_item<HAS_DIV, WPB>(a, lev, i, (size_t)blockIdx.x * 64 + lane, coop, wave, lane, s_part);
 }
 
 // ---- calls with a handful of statements (single Prove): k_solver_few -----------------------------------------------------------------
@@ -587,49 +580,6 @@ __global__ __launch_bounds__(64 * FEW_WAVES) void k_solver_few(SolverFewArgs a) 
     }
 }
 
-// ---- resident batch solver: k_solver_res ----------------------------------------------------------------------------------------------
-// The same lanes-are-proofs work as k_solver, but a whole range of levels in ONE launch of a grid that stays resident (one workgroup of
-// eight waves per CU), levels separated by the device-wide barrier of the latency kernel instead of a kernel boundary.  Why: a batch of
-// a few dozen to a few hundred statements spends its witness stage in 163 (ChaCha20-V3) or 445 (AES-V2) dependent launches of ~26-56 us
-// whose work is a few microseconds — and with several such calls in flight the process is bound by the number of small dependent
-// kernels it can push through its queues.  Wire values move with plain (L2-cached) accesses: the barrier's release
-// writes this XCD's L2 back and its acquire invalidates it, which is what a kernel boundary does too.
-// Work of a level: its first n_long ops are taken by whole workgroups (terms split over the eight waves), the others by single waves;
-// items = (op, group of 64 proofs), consecutive items = consecutive groups of one op.  Forward progress: like k_solver_few (one
-// workgroup per CU by its LDS footprint, launches chained per device by the engine, bounded polling, sync[1] = gave up).
-constexpr int RES_WAVES = 8;
-template <bool HAS_DIV>
-__global__ __launch_bounds__(64 * RES_WAVES) void k_solver_res(SolverResArgs r) {
-    __shared__ uint32_t s_part[3][RES_WAVES][8][64];
-    const SolverArgs& a = r.s;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (__hip_atomic_load(r.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // an earlier launch of this call gave up
-    const uint32_t* lstart = a.sched + 1;
-    const uint32_t G = (uint32_t)(a.batch / 64), NWG = gridDim.x, NW = NWG * RES_WAVES, b = blockIdx.x, wid = b * RES_WAVES + wave;
-    uint32_t epoch = 0;
-    for (uint32_t lev = r.from; lev < r.to; lev++) {
-        const uint32_t l0 = lstart[lev], width = lstart[lev + 1] - l0, nlong = r.level_long[lev];
-        const uint32_t n_long_items = nlong * G, n_short_items = (width - nlong) * G;
-        const uint32_t KL = n_long_items > b ? (n_long_items - b + NWG - 1) / NWG : 0u;                          // uniform over the workgroup
-        const uint32_t KS = n_short_items > b * RES_WAVES ? (n_short_items - b * RES_WAVES + NW - 1) / NW : 0u;  // the workgroup's first wave has the most
-#pragma unroll 1
-        for (uint32_t k = 0; k < KL + KS; k++) {
-            const bool coop = k < KL;
-            const uint32_t it = coop ? b + k * NWG : wid + (k - KL) * NW;
-            if (coop || it < n_short_items) {
-                const uint32_t opi = (coop ? 0u : nlong) + it / G, g = it % G;
-                solver_item<HAS_DIV, RES_WAVES>(a, lev, l0 + opi, (size_t)g * 64 + lane, coop, wave, lane, s_part);
-            }
-            if (coop) __syncthreads();      // the partial sums in LDS are free for the workgroup's next op
-        }
-        if (lev + 1 == r.to) break;
-        if (!few_grid_barrier(r.sync, ++epoch * (NWG + r.test_missing), nullptr, r.poll_limit)) {
-            if (threadIdx.x == 0) atomicOr(r.sync + 1, 1u);      // the host solves the call again, one launch per level
-            return;
-        }
-    }
-}
-
 // OP_COUNT (logderivarg.countHint): out[i] = number of query rows equal to table row i.  One wave per (64 proofs, op); the
 // 256 x 64-lane histogram lives in LDS (32 KiB).  Table rows are constants (index i, value T[i]) — shape checked on the host,
 // index column checked by k_check_count_tables at InitAlgorithm — so a query is matched by reading row `index` directly.
@@ -835,14 +785,6 @@ void launch_solver_few(const SolverFewArgs& a, int has_div, uint32_t workgroups,
     if (has_div) hipLaunchKernelGGL(k_solver_few<true>, dim3(workgroups), dim3(64 * FEW_WAVES), dyn, s, a);
     else hipLaunchKernelGGL(k_solver_few<false>, dim3(workgroups), dim3(64 * FEW_WAVES), dyn, s, a);
 }
-void launch_solver_resident(const SolverResArgs& r, uint32_t workgroups, hipStream_t s) {
-    if (r.from >= r.to || !workgroups) return;
-    // 48 KiB of static LDS (the partial sums) + 40 KiB of unused dynamic LDS: more than half of a CU's 160 KiB, so no two workgroups share a CU
-    constexpr size_t lds = 40 * 1024;
-    if (r.s.has_div) hipLaunchKernelGGL(k_solver_res<true>, dim3(workgroups), dim3(64 * RES_WAVES), lds, s, r);
-    else hipLaunchKernelGGL(k_solver_res<false>, dim3(workgroups), dim3(64 * RES_WAVES), lds, s, r);
-}
-
 void launch_solver_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
     if (!level_width) return;
     const uint32_t n_short = level_width - a.n_long;

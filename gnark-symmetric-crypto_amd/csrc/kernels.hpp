@@ -73,12 +73,6 @@ struct SolverFewArgs {
     unsigned long long* trace;                      // diagnostics (GSC_SOLVER_TRACE): per level stamps of workgroup 0 (100 MHz clock: level in, first item done, workgroup done, released, all arrived, acquired), or nullptr
 };
 void launch_solver_few(const SolverFewArgs& a, int has_div, uint32_t workgroups, hipStream_t s);
-// Levels [from, to) (none of them an OP_COUNT level) of the lanes-are-proofs solver in ONE launch of a resident grid (k_solver_res):
-// device-wide barriers instead of kernel boundaries.  level_long: per level the number of leading long ops (device copy of
-// SolverProgram::level_long); sync: two words as for SolverFewArgs (word 0 zeroed before every launch, word 1 once per call);
-// workgroups: at most the device's CU count (every workgroup must be resident).
-struct SolverResArgs { SolverArgs s; uint32_t from, to; const uint32_t* level_long; uint32_t* sync; uint32_t poll_limit, test_missing; };
-void launch_solver_resident(const SolverResArgs& r, uint32_t workgroups, hipStream_t s);
 // same for a level made of OP_COUNT ops (LDS histogram kernel)
 void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStream_t s);
 // the same for the first nproofs columns of a latency-path call: lanes = queries (FewProgram::count_ops / count_qoff; first_op = count_first[level])
