@@ -115,7 +115,8 @@ __device__ __forceinline__ void dif_stage(const Tile& t, uint32_t bf, uint32_t q
     const uint32_t ex = (gidx<STRIDED>(e1, Llo, tile_id) & (hg - 1)) << s;
     const fe9 u = t.get(e1, q), v = t.get(e2, q);
     t.put(e1, q, carry<REDUCE>(F::add(u, v), pl.qr));
-    t.put(e2, q, mulw<REDUCE>(F::sub(u, v), pl.tw_inv, ex, pl.qr));
+    if (s + 1 == L) t.put(e2, q, carry<REDUCE>(F::sub(u, v), pl.qr));      // wave-uniform: the last stage, every twiddle is 1
+    else t.put(e2, q, mulw<REDUCE>(F::sub(u, v), pl.tw_inv, ex, pl.qr));
 }
 // stages s and s+1 on elements e0 + {0, 1, 2, 3} * he2 (he2 = tile half of stage s+1): stage s pairs (e0,e2), (e1,e3), stage s+1 (e0,e1), (e2,e3)
 template <bool STRIDED, bool REDUCE>
@@ -166,7 +167,7 @@ __device__ __forceinline__ void dit_stage(const Tile& t, uint32_t bf, uint32_t q
     const uint32_t e1 = 2 * bf - (bf & (he - 1)), e2 = e1 + he;
     const uint32_t ex = (gidx<STRIDED>(e1, Llo, tile_id) & ((1u << s) - 1)) << (L - 1 - s);
     const fe9 u = F::norm(t.get(e1, q));
-    const fe9 v = mulw<false>(t.get(e2, q), pl.tw_fwd, ex, pl.qr);
+    const fe9 v = s == 0 ? F::norm(t.get(e2, q)) : mulw<false>(t.get(e2, q), pl.tw_fwd, ex, pl.qr);      // wave-uniform: stage 0, every twiddle is 1
     t.put(e1, q, F::add(u, v)); t.put(e2, q, F::sub(u, v));
 }
 // stages s and s+1 on elements e0 + {0, 1, 2, 3} * he1 (he1 = tile half of stage s): stage s pairs (e0,e1), (e2,e3), stage s+1 (e0,e2), (e1,e3)

@@ -80,6 +80,58 @@ def test_the_timed_configuration_proves_8192_statements_bit_exactly(gsc, oracle,
     assert len({proofs[196 * k:196 * k + 164] for k in range(n)}) == n
 
 
+_CHILD_AES = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import bench, gsc_loader
+import torch
+free, total = torch.cuda.mem_get_info(0)
+assert free > 235e9, "the AES bench configuration needs ~225 GB of device memory; only %.0f GB are free" % (free / 1e9)
+g = gsc_loader.load()
+algo, name = int(sys.argv[5]), sys.argv[6]
+assert g.init_algorithm(algo, open(sys.argv[7], "rb").read(), bench.golden("r1cs." + name))
+d = g.describe(algo)
+print("DESCRIBE", d)
+assert "window_z=15 " in d and "window_w=15 " in d and "max_batch=1024 " in d and "lanes=2 " in d, d
+n = 1024
+recs = bench.provable(bench.xoshiro_records(n, 0xAE5 << 20), name)
+g.set_deterministic_randomness(int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[3]) ^ 0x5555)
+ok, proofs, lens, cts = g.prove_raw(algo, recs, n)
+assert ok == n and set(lens) == {196}, (ok, set(lens))
+open(sys.argv[2], "wb").write(recs + proofs + cts)
+print("CHILD-OK")
+"""
+
+
+def test_the_timed_aes128_configuration_proves_1024_statements_bit_exactly(gsc, oracle, aes_keys, tmp_path):
+    # the same for `bench.py --workload aes128` (BASELINE config 3 / 5): Z digits and wide-wire digits of c = 15 (137 + 42 GB of rows), two lanes of
+    # 1024 proofs.  Keys: the oracle's Setup for the reference's r1cs.aes128 (the reference ships no pk.aes128; parity against gnark is unpinned for
+    # AES, tests/test_gpu_aes.py) — three proofs byte for byte against the oracle, all 1024 through libverify.so under the matching vk.
+    sys.path.insert(0, ROOT)
+    import bench
+    n = 1024
+    r, s = 0x1234567, 0xabcdef0123456789abcdef
+    r1cs, pkb, vkb = aes_keys["aes128"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GSC_")}
+    env.update(bench.engine_env("aes128", n))
+    env["GSC_ENABLE_TEST_HOOKS"] = "1"
+    out_path = str(tmp_path / "out.bin")
+    p = subprocess.run([sys.executable, "-c", _CHILD_AES, ROOT, out_path, str(r), str(s), "1", "aes128", os.path.join(ROOT, "build", "keys", "pk.aes128")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "CHILD-OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+    blob = open(out_path, "rb").read()
+    recs, proofs, cts = blob[:112 * n], blob[112 * n:112 * n + 196 * n], blob[112 * n + 196 * n:]
+    cs, pk = oracle.R1CS(r1cs), oracle.ProvingKey(pkb)
+    for k in (0, 63, 1023):
+        rec = recs[112 * k:112 * (k + 1)]
+        want, want_ct = oracle.prove(cs, pk, "aes-128-ctr", rec[:16], rec[32:44], int.from_bytes(rec[44:48], "little"), rec[48:], r, s, r ^ 0x5555)
+        assert cts[64 * k:64 * k + 64] == want_ct and proofs[196 * k:196 * k + 196] == want, k
+    assert gsc.init_verifier(1, vkb)
+    res = bench.verify_items(gsc, [("aes-128-ctr", proofs[196 * k:196 * k + 196], bench.signals_of("aes128", recs[112 * k:112 * (k + 1)], cts[64 * k:64 * k + 64])) for k in range(n)],
+                             min(32, len(os.sched_getaffinity(0))))
+    assert all(res), [k for k, v in enumerate(res) if not v][:10]
+
+
 def _bench_line(*args):
     import json
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + list(args), env=dict(os.environ), capture_output=True, text=True, timeout=900)
