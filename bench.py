@@ -97,13 +97,14 @@ def synthetic_records(n, seed):
     return xoshiro_records(n, int(seed) << 32)
 
 
-def engine_env(workload, per_algo):
+def engine_env(workload, per_algo, share=1):
     """The engine configuration a timed run uses (environment read by libprove at InitAlgorithm).  One place, so that the test of the
     timed configuration (tests/test_gpu_00_bench_config.py) starts its prover with exactly these settings."""
     env = {"GSC_MAX_BATCH": str(max(64, (per_algo + 63) // 64 * 64))}
-    if workload != "mixed":      # one algorithm alone on the device: widest Z digits that fit (ChaCha c = 16: 69 GB; AES c = 15: 137 GB); mixed keeps the
-        env["GSC_Z_TABLE_GB"] = "140"      # library defaults, under which all three algorithms are resident at once (3 x (48 + 16) GB)
-        env["GSC_W_TABLE_GB"] = "48"       # AES-V2 wide wires: c = 15 (42 GB) instead of 14
+    if workload != "mixed":      # one algorithm alone on the device: widest Z digits that fit (ChaCha c = 17: 137 GB; AES c = 15: 137 GB); mixed keeps the
+        env["GSC_Z_TABLE_GB"] = str(140 // share)      # library defaults, under which all three algorithms are resident at once (3 x (48 + 16) GB)
+        env["GSC_W_TABLE_GB"] = str(48 // share)       # AES-V2 wide wires: c = 15 (42 GB) instead of 14
+        # share > 1: several engine replicas on ONE device (the one-GPU rehearsal of --in-library --devices 0,0) split its memory
     return env
 
 
@@ -374,7 +375,8 @@ def main():
         os.environ["GSC_DEVICE"] = str(local_rank)
     names = ["chacha20", "aes128", "aes256"] if workload == "mixed" else [workload]
     per_algo = B if workload != "mixed" else (B + 2) // 3
-    for k, v in engine_env(workload, per_algo).items():
+    share = max(devices.count(d) for d in devices) if args.in_library else 1
+    for k, v in engine_env(workload, per_algo, share).items():
         os.environ.setdefault(k, v)
     import torch
     import torch.distributed as dist

@@ -48,7 +48,7 @@ EngineConfig config_from_env() {
     if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; }
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
-    if ((c.window_z && (c.window_z < 4 || c.window_z > 16)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_* must be in [4,16]");
+    if ((c.window_z && (c.window_z < 4 || c.window_z > MSM_MAX_WINDOW)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_Z must be in [4,17], GSC_WINDOW_W in [4,16]");
     return c;
 }
 

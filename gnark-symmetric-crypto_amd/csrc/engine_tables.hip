@@ -328,7 +328,7 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
     // Digit widths: explicit (GSC_WINDOW_Z / GSC_WINDOW_W) or the largest that keeps the tables inside the per-algorithm HBM
     // budget (the defaults leave room for all three algorithms of the reference on one 288 GB device: 3 x (48 + 16) GB).
     // Z: uniform rows of 2^(c-1) entries of 64 B: c = 16 is 69 GB for ChaCha20-V3 (2^15 - 1 bases), c = 14 is 69 GB for AES-V2 (2^17 - 1)
-    if (!cfg.window_z) { cfg.window_z = 4; for (int c = 16; c >= 4; c--) if ((double)rowsZ.size() * (double)((size_t)1 << (c - 1)) * 64.0 <= cfg.z_table_gb * 1e9) { cfg.window_z = c; break; } }
+    if (!cfg.window_z) { cfg.window_z = 4; for (int c = MSM_MAX_WINDOW; c >= 4; c--) if ((double)rowsZ.size() * (double)((size_t)1 << (c - 1)) * 64.0 <= cfg.z_table_gb * 1e9) { cfg.window_z = c; break; } }
     if (!cfg.window_w) {      // wire sets: only the wide wires that get the windowed kernel (more than EXPAND_MAX per set) pay for c
         auto wide_of = [&](const std::vector<uint32_t>& rows) {
             size_t k = 0;
@@ -393,7 +393,7 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
             if (o2 * 64 > dg) dg = o2 * 64;
             part(0, ((m.nflat + 7) / 8 + 63) / 64 + (o2 + 63) / 64, 64);
         }
-        if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, WIN_SLICE, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b; if (d > dg) dg = d; }
+        if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, WIN_SLICE, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b * msm_digit_words(m.c); if (d > dg) dg = d; }
     };
     MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew};
     for (size_t b = 64; b <= B; b += 64) {

@@ -51,8 +51,9 @@ __device__ __forceinline__ bool sign_normalise(fe& s) {
 // digits[(j * noct + o) * batch + p] = {e_{8o,j}, ..., e_{8o+7,j}} of proof p.  MONT: the scalars are Montgomery residues of wire
 // values (sign-normalised first: wires are mostly tiny or -tiny); otherwise canonical integers below r (the quotient h).
 // The digit of a negated scalar is negated here, so the MSM kernel only ever sees sign(e) and |e|; the split threshold moves by
-// one for negated scalars so that every stored digit lies in [-D, D-1] (int16 also for c = 16).
-template <bool MONT>
+// one for negated scalars so that every stored digit lies in [-D, D-1] (int16 also for c = 16).  WIDE (c = 17: digits of up to 17 bits + sign):
+// eight int32 per octet, two 16-byte words side by side — digits[2 * index] and digits[2 * index + 1].
+template <bool MONT, bool WIDE>
 __global__ __launch_bounds__(64) void k_recode(MsmRecodeArgs a) {
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x, o = blockIdx.y;
     const size_t noct = (a.nbases + 7) / 8;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(64) void k_recode(MsmRecodeArgs a) {
     }
     const uint32_t c = (uint32_t)a.c, cmask = (1u << c) - 1, D = 1u << (c - 1);
     for (int j = 0; j < a.nwin; j++) {
-        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             uint32_t raw = (s[i].l[0] & cmask) + ((carry >> i) & 1u);
@@ -79,9 +80,11 @@ __global__ __launch_bounds__(64) void k_recode(MsmRecodeArgs a) {
             int32_t d = (int32_t)raw;
             if (raw >= D + (ng ? 1u : 0u)) { d -= (int32_t)(1u << c); carry |= 1u << i; } else carry &= ~(1u << i);
             if (ng) d = -d;
-            w[i >> 1] |= ((uint32_t)d & 0xFFFFu) << (16 * (i & 1));
+            if (WIDE) w[i] = (uint32_t)d; else w[i >> 1] |= ((uint32_t)d & 0xFFFFu) << (16 * (i & 1));
         }
-        a.digits[((size_t)j * noct + o) * a.batch + p] = make_uint4(w[0], w[1], w[2], w[3]);
+        const size_t at = ((size_t)j * noct + o) * a.batch + p;
+        if (WIDE) { a.digits[2 * at] = make_uint4(w[0], w[1], w[2], w[3]); a.digits[2 * at + 1] = make_uint4(w[4], w[5], w[6], w[7]); }
+        else a.digits[at] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -185,24 +188,33 @@ __device__ __forceinline__ Aff9<Fp2x> unpack_aff(const RawAff<Fp2x>& r, bool neg
 // Software pipelining: the digits of the NEXT octet of bases and the table entry of the NEXT base are requested before the
 // current mixed addition (~2 300 instructions) starts, so neither the coalesced digit stream nor the 64-byte random gathers
 // are on the critical path.  Uniform rows: entry d - 1 of base k is table[k * D + d - 1].
-template <class F, bool EXACT>
+// digit i (wave-uniform i) of an octet: eight int16 in one 16-byte word, or (WIDE) eight int32 in two
+template <bool WIDE> __device__ __forceinline__ int32_t octet_digit(const uint4& w0, const uint4& w1, uint32_t i) {
+    if (WIDE) {
+        const uint4& w = (i & 4) ? w1 : w0;
+        return (int32_t)((i & 2) ? ((i & 1) ? w.w : w.z) : ((i & 1) ? w.y : w.x));
+    }
+    const uint64_t lo = (uint64_t)w0.x | ((uint64_t)w0.y << 32), hi = (uint64_t)w0.z | ((uint64_t)w0.w << 32);
+    return (int32_t)(int16_t)(uint16_t)(((i & 4) ? hi : lo) >> (16 * (i & 3)));
+}
+template <class F, bool EXACT, bool WIDE>
 __device__ __forceinline__ Xyzz9<F> accumulate_window(const MsmWinArgs& a, size_t k0, size_t k1, uint32_t j, size_t p) {
     using C = Curve9<F>;
+    constexpr size_t DW = WIDE ? 2 : 1;                     // 16-byte words per (octet, proof)
     const size_t noct = (a.nbases + 7) / 8, D = (size_t)1 << (a.c - 1);
     const fe* table = reinterpret_cast<const fe*>(a.table);
-    const uint4* dig = a.digits + ((size_t)j * noct + k0 / 8) * a.batch + p;
+    const uint4* dig = a.digits + (((size_t)j * noct + k0 / 8) * a.batch + p) * DW;
     Xyzz9<F> acc = C::infinity();
     RawAff<F> pend = {}; int32_t dp = 0;                    // table entry fetched for the previous base, its digit (0: none)
-    uint4 cur = *dig;
+    uint4 cur = dig[0], cur1 = WIDE ? dig[1] : make_uint4(0, 0, 0, 0);
     for (size_t kk = k0; kk < k1; kk += 8) {
-        dig += a.batch;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (kk + 8 < k1) nxt = *dig;
-        const uint64_t lo = (uint64_t)cur.x | ((uint64_t)cur.y << 32), hi = (uint64_t)cur.z | ((uint64_t)cur.w << 32);
+        dig += a.batch * DW;
+        uint4 nxt = make_uint4(0, 0, 0, 0), nxt1 = make_uint4(0, 0, 0, 0);
+        if (kk + 8 < k1) { nxt = dig[0]; if (WIDE) nxt1 = dig[1]; }
         const uint32_t lim = k1 - kk < 8 ? (uint32_t)(k1 - kk) : 8u;
 #pragma unroll 1
         for (uint32_t i = 0; i < lim; i++) {
-            const int32_t d = (int32_t)(int16_t)(uint16_t)(((i & 4) ? hi : lo) >> (16 * (i & 3)));
+            const int32_t d = octet_digit<WIDE>(cur, cur1, i);
             // The gather is unconditional (a zero digit fetches entry 0 and drops it): a load inside a branch would have to be
             // waited for at the join, i.e. before the addition it is meant to overlap with.
             const int32_t mag = d < 0 ? -d : d;
@@ -210,14 +222,14 @@ __device__ __forceinline__ Xyzz9<F> accumulate_window(const MsmWinArgs& a, size_
             if (dp) acc = C::template madd<EXACT>(acc, unpack_aff(pend, dp < 0));
             pend = e; dp = d;
         }
-        cur = nxt;
+        cur = nxt; cur1 = nxt1;
     }
     if (dp) acc = C::template madd<EXACT>(acc, unpack_aff(pend, dp < 0));
     return acc;
 }
 
 // grid: nslices * nwin * (batch / 64) workgroups of one wave.  partial[(slice * nwin + j) * batch + p]
-template <class F>
+template <class F, bool WIDE>
 __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArgs a) {      // G1: three waves per SIMD (<= 168 VGPRs)
     using C = Curve9<F>;
     // XCD-aware order: workgroups go round-robin over the 8 XCDs by linear id and each XCD has its own L2.  Every wave of a slice
@@ -232,10 +244,10 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArg
     const size_t k0 = slice * a.per < a.nbases ? slice * a.per : a.nbases, k1 = k0 + a.per < a.nbases ? k0 + a.per : a.nbases;
     Xyzz9<F> acc = C::infinity();
     if (k0 < k1) {
-        acc = accumulate_window<F, false>(a, k0, k1, j, p);
+        acc = accumulate_window<F, false, WIDE>(a, k0, k1, j, p);
         // A degenerate step (accumulator == +-entry) zeroes ZZ for good; it cannot be told from a genuine point at infinity
         // without the exact tests, so the (very rare) lane is recomputed with them.
-        if (!acc.inf && F::is_zero(acc.zz)) acc = accumulate_window<F, true>(a, k0, k1, j, p);
+        if (!acc.inf && F::is_zero(acc.zz)) acc = accumulate_window<F, true, WIDE>(a, k0, k1, j, p);
     }
     C::store_xyzz(reinterpret_cast<fe*>(a.partial) + ((slice * a.nwin + j) * a.batch + p) * (4 * F::WORDS), acc);
 }
@@ -262,9 +274,11 @@ __global__ __launch_bounds__(64) void k_msm_win_few(MsmWinArgs a) {
     for (size_t kb = k0; kb < k1; kb += 64) {
         const size_t k = kb + lane;
         if (k < k1) {
-            const uint4 w = a.digits[((size_t)j * noct + k / 8) * a.batch + p];
-            const uint32_t s = (uint32_t)(k & 7), word = s < 2 ? w.x : s < 4 ? w.y : s < 6 ? w.z : w.w;
-            const int32_t d = (int32_t)(int16_t)(uint16_t)(word >> (16 * (s & 1)));
+            const size_t at = ((size_t)j * noct + k / 8) * a.batch + p;
+            const uint32_t s = (uint32_t)(k & 7);
+            int32_t d;
+            if (a.c > 16) { const uint4 w = a.digits[2 * at + (s >> 2)]; d = (int32_t)((s & 2) ? ((s & 1) ? w.w : w.z) : ((s & 1) ? w.y : w.x)); }      // wide digits (k_recode)
+            else { const uint4 w = a.digits[at]; const uint32_t word = s < 2 ? w.x : s < 4 ? w.y : s < 6 ? w.z : w.w; d = (int32_t)(int16_t)(uint16_t)(word >> (16 * (s & 1))); }
             if (d) {
                 const int32_t mag = d < 0 ? -d : d;
                 const Aff9<F> e = unpack_aff(load_raw<F>(table + (k * D + (size_t)(mag - 1)) * (2 * F::WORDS)), d < 0);
@@ -555,8 +569,9 @@ void launch_fixed_mul_g2(const G2Aff* table, int c, int nwin, const fe* scalars,
 void launch_msm_recode(const MsmRecodeArgs& a, hipStream_t s) {
     if (!a.nbases) return;
     const dim3 grid((unsigned)(a.batch / 64), (unsigned)((a.nbases + 7) / 8));
-    if (a.mont) hipLaunchKernelGGL(k_recode<true>, grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(k_recode<false>, grid, dim3(64), 0, s, a);
+    if (a.c > 16) { if (a.mont) hipLaunchKernelGGL((k_recode<true, true>), grid, dim3(64), 0, s, a); else hipLaunchKernelGGL((k_recode<false, true>), grid, dim3(64), 0, s, a); }
+    else if (a.mont) hipLaunchKernelGGL((k_recode<true, false>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_recode<false, false>), grid, dim3(64), 0, s, a);
 }
 void launch_msm_recode_flat_few(const MsmFlatRecodeArgs& a, size_t nproofs, hipStream_t s) {
     if (a.nbases) hipLaunchKernelGGL(k_recode_flat_few, dim3((unsigned)(((a.nbases + 7) / 8 + 63) / 64), (unsigned)nproofs), dim3(64), 0, s, a);
@@ -566,8 +581,14 @@ void launch_msm_flat_few_g2(const MsmFlatArgs& a, size_t nproofs, hipStream_t s)
 void launch_msm_recode_flat(const MsmFlatRecodeArgs& a, hipStream_t s) {
     if (a.nbases) hipLaunchKernelGGL(k_recode_flat, dim3((unsigned)(a.batch / 64), (unsigned)((a.nbases + 7) / 8)), dim3(64), 0, s, a);
 }
-void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_win<Fp29f>, dim3((unsigned)(a.nslices * a.nwin * (a.batch / 64))), dim3(64), 0, s, a); }
-void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_win<Fp2x>, dim3((unsigned)(a.nslices * a.nwin * (a.batch / 64))), dim3(64), 0, s, a); }
+void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)(a.nslices * a.nwin * (a.batch / 64)));
+    if (a.c > 16) hipLaunchKernelGGL((k_msm_win<Fp29f, true>), grid, dim3(64), 0, s, a); else hipLaunchKernelGGL((k_msm_win<Fp29f, false>), grid, dim3(64), 0, s, a);
+}
+void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)(a.nslices * a.nwin * (a.batch / 64)));
+    if (a.c > 16) hipLaunchKernelGGL((k_msm_win<Fp2x, true>), grid, dim3(64), 0, s, a); else hipLaunchKernelGGL((k_msm_win<Fp2x, false>), grid, dim3(64), 0, s, a);
+}
 void launch_msm_win_few_g1(const MsmWinArgs& a, size_t nproofs, hipStream_t s) { hipLaunchKernelGGL(k_msm_win_few<Fp29f>, dim3((unsigned)(a.nslices * a.nwin), (unsigned)nproofs), dim3(64), 0, s, a); }
 void launch_msm_win_few_g2(const MsmWinArgs& a, size_t nproofs, hipStream_t s) { hipLaunchKernelGGL(k_msm_win_few<Fp2x>, dim3((unsigned)(a.nslices * a.nwin), (unsigned)nproofs), dim3(64), 0, s, a); }
 void launch_msm_flat_g1(const MsmFlatArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_msm_flat<Fp29f>, dim3((unsigned)(a.nslices * (a.batch / 64))), dim3(64), 0, s, a); }

@@ -113,7 +113,10 @@ void launch_shift_bases_g1(const G1Aff* in, const uint32_t* src, const uint32_t*
 void launch_shift_bases_g2(const G2Aff* in, const uint32_t* src, const uint32_t* shift, size_t n, G2Aff* out, hipStream_t s);
 
 // Windowed sets.  Signed-digit recoding once per batch: digits[(j * noct + o) * batch + p] holds the eight int16 digits
-// e_{8o..8o+7, j} of proof p (noct = ceil(nbases / 8); bases beyond nbases get zero digits).  nwin = msm_windows(c).
+// e_{8o..8o+7, j} of proof p (noct = ceil(nbases / 8); bases beyond nbases get zero digits).  nwin = msm_windows(c).  c = 17 (MSM_MAX_WINDOW):
+// digits need 18 bits, so an octet takes TWO 16-byte words of eight int32 — digits[2 * index], digits[2 * index + 1]: buffers twice the size.
+constexpr int MSM_MAX_WINDOW = 17;
+inline size_t msm_digit_words(int c) { return c > 16 ? 2 : 1; }      // 16-byte words per (window, octet, proof)
 struct MsmRecodeArgs {
     const fe* scalars; const uint32_t* rows;   // [row][batch]; scalar row per base (nullptr: row k)
     int mont;                                  // 1: Montgomery residues of wire values (sign-normalised before recoding), 0: canonical integers < r

@@ -2,13 +2,14 @@
 the reference's own gate is libraries/core_test.go:171).
 
 The rest of the GPU session runs with small tables (conftest.py: GSC_Z_TABLE_GB=24 -> Z digits of c = 14, lanes of 1024 proofs).  The
-driver's bench runs bench.engine_env("chacha20", 8192): c = 16 — the int16 edge of the digit recoder (digits in [-2^15, 2^15 - 1], row
-index 2^15 - 1) —, 69 GB of Z rows, one lane of 8192 proofs, 128 slices x 16 windows x 128 proof groups.  This test starts a prover
+driver's bench runs bench.engine_env("chacha20", 8192): c = 17 — digits beyond int16, the recoder's wide format of eight int32 per octet
+(digits in [-2^16, 2^16 - 1], row index 2^16 - 1) —, 137 GB of Z rows, one lane of 8192 proofs, 128 slices x 15 windows x 128 proof
+groups; nothing else in the suite reaches that format.  This test starts a prover
 process with exactly that environment, proves 8192 statements in one call with (r, s) fixed, compares eight of them byte for byte
 with the CPU oracle (first / last wave and the wave boundaries 63 | 64, 4095 | 4096, 8127 | 8128) and verifies ALL of them with
 libverify.so under the reference's vk.chacha20.
 
-The file sorts before every other GPU test: its child process needs ~125 GB of the device, which the session's own algorithms
+The file sorts before every other GPU test: its child processes need ~200 GB of the device, which the session's own algorithms
 (~170 GB once the AES tests have run) would not leave."""
 import base64
 import os
@@ -28,12 +29,12 @@ sys.path.insert(0, sys.argv[1])
 import bench, gsc_loader
 import torch
 free, total = torch.cuda.mem_get_info(0)
-assert free > 135e9, "the bench configuration needs ~125 GB of device memory; only %.0f GB are free (run this test before the session loads its own algorithms)" % (free / 1e9)
+assert free > 205e9, "the bench configuration needs ~200 GB of device memory; only %.0f GB are free (run this test before the session loads its own algorithms)" % (free / 1e9)
 g = gsc_loader.load()
 assert g.init_algorithm(0, bench.golden("pk.chacha20"), bench.golden("r1cs.chacha20"))
 d = g.describe(0)
 print("DESCRIBE", d)
-assert "window_z=16 " in d and "max_batch=8192 " in d and "lanes=1 " in d, d
+assert "window_z=17 " in d and "max_batch=8192 " in d and "lanes=1 " in d, d
 n = 8192
 recs = bench.xoshiro_records(n, 0x7E57 << 20)
 g.set_deterministic_randomness(int(sys.argv[3]), int(sys.argv[4]), 0)
