@@ -21,7 +21,7 @@ write, ms_w, n_w = per_launch(sys.argv[2], ["WRITE_SIZE"])
 tcc, ms_t, n_t = per_launch(sys.argv[3], ["TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum"])
 c = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 batch = int(sys.argv[6]) if len(sys.argv) > 6 else 8192
-nbases, nwin = 32767, {16: 16, 15: 17, 14: 19, 13: 20}.get(c, math.ceil(254 / c))
+nbases, nwin = 32767, {17: 15, 16: 16, 15: 17, 14: 19, 13: 20}.get(c, math.ceil(254 / c))
 E = 1 << (c - 1); g = 384 * 64.0                       # entries per row; lanes of one XCD's 384 resident waves gathering from the same row
 model = 1.0 - (E / g) * (1.0 - math.exp(-g / E))
 out = {
@@ -39,8 +39,9 @@ out = {
              "calibrated on a known byte count with tools/ubench_gather.hip in round 2 (factor 0.9999: FETCH_SIZE = TCC_EA0_RDREQ x 64 B).  "
              "hit_rate_model: the L2 hit rate this access pattern CAN have — every resident wave of an XCD (32 CUs x 4 SIMDs x 3 waves x 64 lanes = g = 24 576 "
              "lanes) gathers a uniformly random one of the E = 2^(c-1) entries of the row the XCD is on; distinct entries touched = E (1 - exp(-g / E)), so "
-             "hit = 1 - (E / g)(1 - exp(-g / E)): 0.30 at c = 16, 0.83 at c = 13 (measured 0.26 and 0.74).  The other 1 664 of a slice's 2 048 waves come by "
-             "after the row has left the 4 MiB L2 (a slice streams 256 MiB of rows through it), so keeping the resident waves in step — they already are, by "
+             "hit = 1 - (E / g)(1 - exp(-g / E)): 0.17 at c = 17, 0.30 at c = 16, 0.83 at c = 13 — a ceiling (lanes perfectly in step on one row); measured at c = 16: 0.26 (round 2) and 0.21 (round 3), "
+             "at c = 13: 0.74.  The other waves of a slice (1 920 windows x proof groups at c = 17, 384 resident) come by "
+             "after the row has left the 4 MiB L2 (a slice streams 256 - 512 MiB of rows through it), so keeping the resident waves in step — they already are, by "
              "construction: same start, same work — cannot raise it; only more lanes per row visit (registers) or shorter rows (more windows, more additions) can.",
 }
 json.dump(out, open(sys.argv[4], "w"), indent=1)
