@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
     Tile t{smem, G * P};
     for (uint32_t e = u4; e < G; e += G / 4) {
         const size_t idx = ((size_t)e << Llo) + g;
-        t.put(e, q, idx < m ? F::load(vec + idx * batch + q0 + q) : F::zero());
+        t.put(e, q, idx < m ? F::unpack(load_fe_nt(vec + idx * batch + q0 + q)) : F::zero());      // the solver's rows: read once
     }
     __syncthreads();
     dif_run<true>(t, u4, q, 0, Lhi, 0, L, Llo, g, pl, G);
