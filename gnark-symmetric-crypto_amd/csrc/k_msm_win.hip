@@ -83,8 +83,8 @@ __global__ __launch_bounds__(64) void k_recode(MsmRecodeArgs a) {
             if (WIDE) w[i] = (uint32_t)d; else w[i >> 1] |= ((uint32_t)d & 0xFFFFu) << (16 * (i & 1));
         }
         const size_t at = ((size_t)j * noct + o) * a.batch + p;
-        if (WIDE) { store_u4_nt(a.digits + 2 * at, make_uint4(w[0], w[1], w[2], w[3])); store_u4_nt(a.digits + 2 * at + 1, make_uint4(w[4], w[5], w[6], w[7])); }
-        else store_u4_nt(a.digits + at, make_uint4(w[0], w[1], w[2], w[3]));
+        if (WIDE) { a.digits[2 * at] = make_uint4(w[0], w[1], w[2], w[3]); a.digits[2 * at + 1] = make_uint4(w[4], w[5], w[6], w[7]); }
+        else a.digits[at] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -206,11 +206,11 @@ __device__ __forceinline__ Xyzz9<F> accumulate_window(const MsmWinArgs& a, size_
     const uint4* dig = a.digits + (((size_t)j * noct + k0 / 8) * a.batch + p) * DW;
     Xyzz9<F> acc = C::infinity();
     RawAff<F> pend = {}; int32_t dp = 0;                    // table entry fetched for the previous base, its digit (0: none)
-    uint4 cur = load_u4_nt(dig), cur1 = WIDE ? load_u4_nt(dig + 1) : make_uint4(0, 0, 0, 0);      // the digit stream is read once: keep the L2 for table rows
+    uint4 cur = dig[0], cur1 = WIDE ? dig[1] : make_uint4(0, 0, 0, 0);
     for (size_t kk = k0; kk < k1; kk += 8) {
         dig += a.batch * DW;
         uint4 nxt = make_uint4(0, 0, 0, 0), nxt1 = make_uint4(0, 0, 0, 0);
-        if (kk + 8 < k1) { nxt = load_u4_nt(dig); if (WIDE) nxt1 = load_u4_nt(dig + 1); }
+        if (kk + 8 < k1) { nxt = dig[0]; if (WIDE) nxt1 = dig[1]; }
         const uint32_t lim = k1 - kk < 8 ? (uint32_t)(k1 - kk) : 8u;
 #pragma unroll 1
         for (uint32_t i = 0; i < lim; i++) {
