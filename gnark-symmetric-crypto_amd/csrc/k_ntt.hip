@@ -38,6 +38,10 @@ constexpr int P = 4;       // proofs per workgroup tile
 //     sum path.  Instead of a comparison chain per butterfly, reduce_top() is applied once per DIF run of >= 4 stages
 //     and once before a kernel stores its tile: it estimates q = floor(value / r) from the top limb (float multiply)
 //     and subtracts the tabulated q*r, leaving a value in (-1.001 r, 2.001 r).
+// Global accesses of these kernels are plain: every vector passes through each kernel once, but non-temporal loads / stores were measured
+// slower here (quotient stage 122 -> 125 ms per 8192 proofs).
+__device__ __forceinline__ fe ld_stream(const fe* p) { return load_fe(p); }
+__device__ __forceinline__ void st_stream(fe* p, const fe& v) { store_fe(p, v); }
 constexpr float INV_TOP_R = 1.0f / 3171407.0f;     // top limb of r is 3171406
 __device__ __forceinline__ fe9 reduce_top(const fe9& x, const int32_t* qr) {
     const fe9 t = F::norm(x);
@@ -56,7 +60,7 @@ __device__ __forceinline__ void store_lazy(fe* p, const fe9& x, const int32_t* q
     const bool lo = t.l[8] < 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) t.l[i] += lo ? F::PK(1, i) : 0;     // + 2r: (-1.001 r, 2.001 r) -> [0, 2.001 r)
-    store_fe(p, F::pack(F::norm(t)));
+    st_stream(p, F::pack(F::norm(t)));
 }
 
 // twiddles are stored already split into limbs: 12 int32 per entry (9 used; 48-byte stride keeps the three 16-byte loads aligned)
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
     Tile t{smem, G * P};
     for (uint32_t e = u4; e < G; e += G / 4) {
         const size_t idx = ((size_t)e << Llo) + g;
-        t.put(e, q, idx < m ? F::unpack(load_fe_nt(vec + idx * batch + q0 + q)) : F::zero());      // the solver's rows: read once
+        t.put(e, q, idx < m ? F::unpack(ld_stream(vec + idx * batch + q0 + q)) : F::zero());
     }
     __syncthreads();
     dif_run<true>(t, u4, q, 0, Lhi, 0, L, Llo, g, pl, G);
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
     Tile t{smem, Cn * P};
     for (uint32_t e = u4; e < Cn; e += Cn / 4) {
         const size_t idx = ((size_t)b << Llo) + e;
-        t.put(e, q, F::load(vec + idx * batch + q0 + q));
+        t.put(e, q, F::unpack(ld_stream(vec + idx * batch + q0 + q)));
     }
     __syncthreads();
     dif_run<false>(t, u4, q, Lhi, L, 0, L, Llo, b, pl, Cn);
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
         const fe* vec = k == 0 ? va : vb;
         for (uint32_t e = u4; e < G; e += G / 4) {
             const size_t idx = ((size_t)e << Llo) + g;
-            t.put(e, q, F::load(vec + idx * batch + q0 + q));
+            t.put(e, q, F::unpack(ld_stream(vec + idx * batch + q0 + q)));
         }
         __syncthreads();
         dit_run<true>(t, u4, q, Llo, L - 1, L, Llo, g, pl, G);
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, co
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t e = u4 + k * (Cn / 4); const size_t idx = ((size_t)b << Llo) + e;
-            t.put(e, q, F::load(vec + idx * batch + q0 + q));
+            t.put(e, q, F::unpack(ld_stream(vec + idx * batch + q0 + q)));
         }
         __syncthreads();
         dif_run<false>(t, u4, q, Lhi, L, 0, L, Llo, b, pl, Cn);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, co
     const fe9 kc = F::load(pl.half_c);
     auto finish = [&](uint32_t e, const fe9& sv) {
         const size_t idx = ((size_t)b << Llo) + e;
-        F::store(vh + idx * batch + q0 + q, F::fmms(sv, kc, t.get(e, q), F::load(pl.scale_out + idx)));
+        st_stream(vh + idx * batch + q0 + q, F::pack(F::freeze(F::fmms(sv, kc, t.get(e, q), F::load(pl.scale_out + idx)))));
     };
     finish(u4, s0); finish(u4 + Cn / 4, s1); finish(u4 + 2 * (Cn / 4), s2); finish(u4 + 3 * (Cn / 4), s3);
 }
