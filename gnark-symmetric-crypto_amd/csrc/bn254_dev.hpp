@@ -251,39 +251,4 @@ DEVFN void store_fe(fe* p, const fe& v) {
     q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
-// Streaming variants (non-temporal: the line is not kept in the caches): for data that is written once and read by a LATER kernel
-// (the solver's A / B / C rows: witness stage 23.0 -> 22.1 ms per 8192 proofs) or read exactly once, so that it does not evict what the
-// kernel does reuse.  Measured and NOT used for the MSM digit streams (recoder stores: MSM stage + 2.4 ms; the Z kernel's digit loads: no change).
-#ifndef GSC_NT
-#define GSC_NT 1
-#endif
-typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
-DEVFN uint4 load_u4_nt(const uint4* p) {
-#if GSC_NT
-    const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-DEVFN void store_u4_nt(uint4* p, const uint4& v) {
-#if GSC_NT
-    nt_u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-    __builtin_nontemporal_store(w, reinterpret_cast<nt_u32x4*>(p));
-#else
-    *p = v;
-#endif
-}
-DEVFN fe load_fe_nt(const fe* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    const uint4 a = load_u4_nt(q), b = load_u4_nt(q + 1);
-    fe r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
-}
-DEVFN void store_fe_nt(fe* p, const fe& v) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    store_u4_nt(q, make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]));
-    store_u4_nt(q + 1, make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]));
-}
-
 }  // namespace bn254

@@ -38,8 +38,8 @@ constexpr int P = 4;       // proofs per workgroup tile
 //     sum path.  Instead of a comparison chain per butterfly, reduce_top() is applied once per DIF run of >= 4 stages
 //     and once before a kernel stores its tile: it estimates q = floor(value / r) from the top limb (float multiply)
 //     and subtracts the tabulated q*r, leaving a value in (-1.001 r, 2.001 r).
-// Global accesses of these kernels are plain: every vector passes through each kernel once, but non-temporal loads / stores were measured
-// slower here (quotient stage 122 -> 125 ms per 8192 proofs).
+// Global accesses of these kernels are plain.  Non-temporal loads / stores (every vector passes through each kernel exactly once) were tried in
+// round 3: quotient stage 122 -> 125 ms per 8192 proofs, and one run of the 2^17-domain parity test failed with them — not pursued, not used.
 __device__ __forceinline__ fe ld_stream(const fe* p) { return load_fe(p); }
 __device__ __forceinline__ void st_stream(fe* p, const fe& v) { store_fe(p, v); }
 constexpr float INV_TOP_R = 1.0f / 3171407.0f;     // top limb of r is 3171406

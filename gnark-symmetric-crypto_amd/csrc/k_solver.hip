@@ -215,9 +215,9 @@ __global__ __launch_bounds__(64 * WPB) void k_solver(SolverArgs a) {
                 else if (uc != 1) wire = Fr::mul(wire, load_fe(a.coeff_inv + uc));
                 store_fe(a.W + (size_t)uw * batch + p, wire);
             }
-            store_fe_nt(a.A + (size_t)cidx * batch + p, va);      // read next by the quotient kernels, never by the solver
-            store_fe_nt(a.B + (size_t)cidx * batch + p, vb);
-            store_fe_nt(a.C + (size_t)cidx * batch + p, vc);
+            store_fe(a.A + (size_t)cidx * batch + p, va);
+            store_fe(a.B + (size_t)cidx * batch + p, vb);
+            store_fe(a.C + (size_t)cidx * batch + p, vc);
         }
     } else if (!coop || wave == 0) {
         if (op == OP_LOOKUP) {                              // [hdr, out0, nIn, table, exprs]: out[e] = table[value of expr e]
