@@ -29,7 +29,7 @@ using namespace bn254;
 namespace {
 
 using F = Fr29;            // radix-2^29 lazy-limb scalar field (bn254_fp29.hpp): 227-instruction products, carry-free add/sub
-constexpr int P = 4;       // proofs per workgroup tile
+constexpr int P = 4;       // proofs per workgroup tile (measured on 8192 proofs, round 3: P = 2 -> 125.5 ms, P = 4 -> 120.3 ms, P = 8 -> 128.9 ms for the quotient stage)
 
 // Ranges inside the transforms (Fr29: R' = 2^261 ~ 169 r, a product a*w with w < r lands in (-|a|/169, |a|/169 + r)):
 //   * limbs: everything written to a tile has |limb| < 2^30 (one lazy add/sub of tight values); an operand is carried
