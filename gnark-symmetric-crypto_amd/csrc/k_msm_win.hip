@@ -230,7 +230,7 @@ __device__ __forceinline__ Xyzz9<F> accumulate_window(const MsmWinArgs& a, size_
 
 // grid: nslices * nwin * (batch / 64) workgroups of one wave.  partial[(slice * nwin + j) * batch + p]
 template <class F, bool WIDE>
-__global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArgs a) {      // G1: three waves per SIMD (<= 168 VGPRs)
+__global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArgs a) {      // G1: three waves per SIMD (<= 168 VGPRs); measured in round 3: four (128 VGPRs, 34 spilled) 272.3 ms, two 272.9 ms — the same
     using C = Curve9<F>;
     // XCD-aware order: workgroups go round-robin over the 8 XCDs by linear id and each XCD has its own L2.  Every wave of a slice
     // (all windows, all groups of proofs) gathers from the same table rows, so a slice is placed on ONE XCD (consecutive ids there).
