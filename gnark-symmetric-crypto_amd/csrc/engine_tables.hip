@@ -328,7 +328,22 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
     // Digit widths: explicit (GSC_WINDOW_Z / GSC_WINDOW_W) or the largest that keeps the tables inside the per-algorithm HBM
     // budget (the defaults leave room for all three algorithms of the reference on one 288 GB device: 3 x (48 + 16) GB).
     // Z: uniform rows of 2^(c-1) entries of 64 B: c = 16 is 69 GB for ChaCha20-V3 (2^15 - 1 bases), c = 14 is 69 GB for AES-V2 (2^17 - 1)
-    if (!cfg.window_z) { cfg.window_z = 4; for (int c = MSM_MAX_WINDOW; c >= 4; c--) if ((double)rowsZ.size() * (double)((size_t)1 << (c - 1)) * 64.0 <= cfg.z_table_gb * 1e9) { cfg.window_z = c; break; } }
+    if (!cfg.window_z) {
+        // ... and inside what the device has free right now: the budget is an upper bound, not a promise (another tenant of the device, a host that
+        // loads several algorithms).  Left out of the Z rows: the batch buffers of the lanes (~ 5.7 KiB per wire-or-domain row and proof, see
+        // alloc_lane), the other sets' tables and the latency layouts (their own budgets), and 8 GiB of slack.
+        double budget = cfg.z_table_gb * 1e9;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double nlanes = cfg.lanes > 0 ? cfg.lanes : (cs.has_commitment ? 2 : 1);
+            const double lane = nlanes * (double)cfg.max_batch * ((double)n_wires * 32 + 3.0 * (double)domain_n * 32 + (double)domain_n * 2 * 20 + 1e5) * 1.15;
+            const double others = (cfg.w_table_gb + (cfg.few_path ? cfg.few_z_gb + (cs.has_commitment ? 8 : 0) : 0)) * 1e9 + 8.0 * 1073741824.0;
+            const double room = (double)free_b - lane - others;
+            if (room < budget) budget = room > 0 ? room : 0;
+        }
+        cfg.window_z = 4;
+        for (int c = MSM_MAX_WINDOW; c >= 4; c--) if ((double)rowsZ.size() * (double)((size_t)1 << (c - 1)) * 64.0 <= budget) { cfg.window_z = c; break; }
+    }
     if (!cfg.window_w) {      // wire sets: only the wide wires that get the windowed kernel (more than EXPAND_MAX per set) pay for c
         auto wide_of = [&](const std::vector<uint32_t>& rows) {
             size_t k = 0;

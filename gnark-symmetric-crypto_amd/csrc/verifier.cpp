@@ -47,26 +47,34 @@ struct Fp2 {
 
 // exponents derived from p (computed once)
 struct Consts {
-    u64 sqrt_e[4], pm1_3[4], pm1_2[4]; Fp2 xi, g2, g3, twist_b; Fp three;
-    std::vector<u64> final_exp;      // (p^12 - 1) / r
+    u64 sqrt_e[4], pm1_3[4], pm1_2[4], pm1_6[4]; Fp2 xi, g2, g3, twist_b; Fp three;
+    Fp2 frob1[6]; Fp frob2[6];       // w^(i p) = frob1[i] w^i, w^(i p^2) = frob2[i] w^i  (w^6 = xi)
+    std::vector<int8_t> hard_naf;    // (p^4 - p^2 + 1) / r in non-adjacent form, least significant digit first
+    static std::vector<u64> mul_big(const std::vector<u64>& a, const std::vector<u64>& b) {
+        std::vector<u64> r(a.size() + b.size(), 0);
+        for (size_t i = 0; i < a.size(); i++) { u128 c = 0; for (size_t j = 0; j < b.size(); j++) { c += (u128)a[i] * b[j] + r[i + j]; r[i + j] = (u64)c; c >>= 64; } r[i + b.size()] += (u64)c; }
+        return r;
+    }
     static void div_small(const u64* in, int n, u64 d, u64* out) { u128 rem = 0; for (int i = n - 1; i >= 0; i--) { u128 cur = (rem << 64) | in[i]; out[i] = (u64)(cur / d); rem = cur % d; } }
     Consts() {
         Fp::init(); Fr::init();
         U256 p = Fp::MOD, t = p;
         add_into(t, U256{{1, 0, 0, 0}}); div_small(t.w, 4, 4, sqrt_e);          // (p+1)/4
-        t = p; t.w[0] -= 1; div_small(t.w, 4, 3, pm1_3); div_small(t.w, 4, 2, pm1_2);
+        t = p; t.w[0] -= 1; div_small(t.w, 4, 3, pm1_3); div_small(t.w, 4, 2, pm1_2); div_small(t.w, 4, 6, pm1_6);
         three = Fp::from_u64(3);
         xi = {Fp::from_u64(9), Fp::one()};
         twist_b = Fp2{three, Fp::zero()} * xi.inv();
         g2 = xi.pow(pm1_3, 4); g3 = xi.pow(pm1_2, 4);
-        // (p^12 - 1)/r by schoolbook big-number arithmetic on 64-bit limbs
-        std::vector<u64> acc{1};
-        for (int k = 0; k < 12; k++) {
-            std::vector<u64> nx(acc.size() + 4, 0);
-            for (size_t i = 0; i < acc.size(); i++) { u128 c = 0; for (int j = 0; j < 4; j++) { c += (u128)acc[i] * p.w[j] + nx[i + j]; nx[i + j] = (u64)c; c >>= 64; } size_t q = i + 4; while (c) { c += nx[q]; nx[q] = (u64)c; c >>= 64; q++; } }
-            acc = nx;
-        }
-        acc[0] -= 1;   // p^12 is odd
+        // Frobenius on Fp12 = Fp2[w]/(w^6 - xi): w^p = xi^((p-1)/6) w
+        const Fp2 gam = xi.pow(pm1_6, 4);
+        frob1[0] = Fp2::one(); for (int i = 1; i < 6; i++) frob1[i] = frob1[i - 1] * gam;
+        const Fp nrm = (gam * gam.conj()).a;                                   // w^(p^2) = gam^p gam w = N(gam) w, N(gam) in Fp
+        frob2[0] = Fp::one(); for (int i = 1; i < 6; i++) frob2[i] = frob2[i - 1] * nrm;
+        // hard part of the final exponentiation: (p^4 - p^2 + 1) / r by schoolbook big-number arithmetic on 64-bit limbs
+        const std::vector<u64> pv(p.w, p.w + 4), p2 = mul_big(pv, pv), p4 = mul_big(p2, p2);
+        std::vector<u64> acc = p4;
+        { u128 br = 0; for (size_t i = 0; i < acc.size(); i++) { const u128 d = (u128)acc[i] - (i < p2.size() ? p2[i] : 0) - br; acc[i] = (u64)d; br = (d >> 64) & 1; } }   // - p^2
+        for (size_t i = 0; i < acc.size(); i++) { if (++acc[i]) break; }                                                                                                   // + 1
         // long division by r (256-bit) : shift-subtract
         const U256 r = Fr::MOD; std::vector<u64> q(acc.size(), 0); U256 rem{{0, 0, 0, 0}}; u64 ext = 0;
         for (int bit = (int)acc.size() * 64 - 1; bit >= 0; bit--) {
@@ -75,8 +83,17 @@ struct Consts {
             rem.w[0] = (rem.w[0] << 1) | ((acc[bit / 64] >> (bit % 64)) & 1);
             if (ext || geq(rem, r)) { sub_into(rem, r); q[bit / 64] |= 1ull << (bit % 64); }
         }
-        while (!q.empty() && q.back() == 0) q.pop_back();
-        final_exp = q;
+        if (rem.w[0] | rem.w[1] | rem.w[2] | rem.w[3]) throw std::runtime_error("internal: r does not divide p^4 - p^2 + 1");
+        // non-adjacent form: a third of the digits are non-zero (an inverse is free in the cyclotomic subgroup)
+        q.push_back(0);
+        auto is_zero = [&] { for (u64 x : q) if (x) return false; return true; };
+        while (!is_zero()) {
+            int8_t d = 0;
+            if (q[0] & 1) { d = (q[0] & 2) ? -1 : 1; if (d == 1) q[0] -= 1; else { for (size_t i = 0; i < q.size(); i++) { if (++q[i]) break; } } }
+            hard_naf.push_back(d);
+            for (size_t i = 0; i + 1 < q.size(); i++) q[i] = (q[i] >> 1) | (q[i + 1] << 63);
+            q.back() >>= 1;
+        }
     }
 };
 const Consts& K() { static Consts c; return c; }
@@ -203,26 +220,77 @@ struct Fp12 {
         Fp12 r; for (int k = 0; k < 6; k++) { r.c[k] = t[k]; if (k + 6 < 11) r.c[k] = r.c[k] + t[k + 6] * K().xi; }
         return r;
     }
+    Fp12 sq() const {      // cross products once: 15 products + 6 squarings instead of 36 products
+        Fp2 t[11]; for (auto& x : t) x = Fp2::zero();
+        for (int i = 0; i < 6; i++) { t[2 * i] = t[2 * i] + c[i].sq(); for (int j = i + 1; j < 6; j++) { const Fp2 m = c[i] * c[j]; t[i + j] = t[i + j] + m + m; } }
+        Fp12 r; for (int k = 0; k < 6; k++) { r.c[k] = t[k]; if (k + 6 < 11) r.c[k] = r.c[k] + t[k + 6] * K().xi; }
+        return r;
+    }
+    Fp12 conj6() const { Fp12 r = *this; r.c[1] = r.c[1].neg(); r.c[3] = r.c[3].neg(); r.c[5] = r.c[5].neg(); return r; }      // x^(p^6): w -> -w
+    Fp12 frob() const { Fp12 r; for (int i = 0; i < 6; i++) r.c[i] = c[i].conj() * K().frob1[i]; return r; }                      // x^p
+    Fp12 frob2() const { Fp12 r; for (int i = 0; i < 6; i++) r.c[i] = c[i].scale(K().frob2[i]); return r; }                       // x^(p^2)
+    // 1 / x through Fp6 = Fp2[u]/(u^3 - xi), u = w^2: x = A + w B, 1/x = (A - w B) / (A^2 - u B^2)
+    struct F6 {
+        Fp2 a, b, c;
+        F6 operator*(const F6& o) const { const Fp2& xi = K().xi; return {a * o.a + (b * o.c + c * o.b) * xi, a * o.b + b * o.a + (c * o.c) * xi, a * o.c + b * o.b + c * o.a}; }
+        F6 operator-(const F6& o) const { return {a - o.a, b - o.b, c - o.c}; }
+        F6 mul_u() const { return {c * K().xi, a, b}; }
+        F6 inv() const {
+            const Fp2& xi = K().xi;
+            const Fp2 t0 = a.sq() - (b * c) * xi, t1 = c.sq() * xi - a * b, t2 = b.sq() - a * c;
+            const Fp2 n = (a * t0 + (c * t1 + b * t2) * xi).inv();
+            return {t0 * n, t1 * n, t2 * n};
+        }
+    };
+    Fp12 inv() const {
+        const F6 A{c[0], c[2], c[4]}, B{c[1], c[3], c[5]};
+        const F6 n = (A * A - (B * B).mul_u()).inv(), ra = A * n, rb = B * n;
+        Fp12 r; r.c[0] = ra.a; r.c[2] = ra.b; r.c[4] = ra.c; r.c[1] = rb.a.neg(); r.c[3] = rb.b.neg(); r.c[5] = rb.c.neg();
+        return r;
+    }
 };
 // line through psi(T), psi(Q) evaluated at P (D-type twist, psi(x,y) = (x w^2, y w^3)): yP - lambda xP w + (lambda xT - yT) w^3
 struct Tw { Fp2 x, y; };
 Fp12 line(const Fp2& lam, const Tw& T, const G1& P) { Fp12 l; for (auto& x : l.c) x = Fp2::zero(); l.c[0] = {P.y, Fp::zero()}; l.c[1] = lam.scale(P.x).neg(); l.c[3] = lam * T.x - T.y; return l; }
-Fp12 step_dbl(Tw& T, const G1& P) { Fp2 x2 = T.x.sq(); Fp2 lam = (x2 + x2 + x2) * (T.y + T.y).inv(); Fp12 l = line(lam, T, P); Fp2 x3 = lam.sq() - T.x - T.x; T = {x3, lam * (T.x - x3) - T.y}; return l; }
-Fp12 step_add(Tw& T, const Tw& Q, const G1& P) { Fp2 lam = (Q.y - T.y) * (Q.x - T.x).inv(); Fp12 l = line(lam, T, P); Fp2 x3 = lam.sq() - T.x - Q.x; T = {x3, lam * (T.x - x3) - T.y}; return l; }
-Fp12 miller(const G1& P, const G2& Q) {
-    Fp12 f = Fp12::one();
-    if (P.inf || Q.inf) return f;
-    const u64 loop[2] = {0x9d797039be763ba8ull, 1};     // 6x + 2, x = 4965661367192848881
-    Tw T{Q.x, Q.y}; const Tw Qa = T;
-    for (int i = 63; i >= 0; i--) { f = f * f; f = f * step_dbl(T, P); if ((loop[i / 64] >> (i % 64)) & 1) f = f * step_add(T, Qa, P); }
-    Tw Q1{Qa.x.conj() * K().g2, Qa.y.conj() * K().g3}; Tw Q2{Q1.x.conj() * K().g2, (Q1.y.conj() * K().g3).neg()};
-    f = f * step_add(T, Q1, P); f = f * step_add(T, Q2, P);
-    return f;
-}
+// Product of pairings == 1 ?  One Miller loop for all pairs: the accumulator is squared once per step whatever the number of pairs,
+// and the slopes of a step share ONE field inversion (Montgomery's trick over Fp2).  Final exponentiation (p^12 - 1) / r =
+// (p^6 - 1)(p^2 + 1) * (p^4 - p^2 + 1) / r: the first two factors by conjugation, one inversion and a Frobenius map, the last by
+// square-and-multiply over its non-adjacent form (761 squarings, ~250 products; inverse = conjugate in the cyclotomic subgroup).
 bool pairing_product_is_one(const std::vector<std::pair<G1, G2>>& v) {
-    Fp12 acc = Fp12::one(); for (auto& pq : v) acc = acc * miller(pq.first, pq.second);
-    const auto& e = K().final_exp; Fp12 r = Fp12::one();
-    for (int i = (int)e.size() * 64 - 1; i >= 0; i--) { r = r * r; if ((e[i / 64] >> (i % 64)) & 1) r = r * acc; }
+    struct Pair { G1 P; Tw T, Q; };
+    std::vector<Pair> ps;
+    for (auto& pq : v) if (!pq.first.inf && !pq.second.inf) ps.push_back({pq.first, {pq.second.x, pq.second.y}, {pq.second.x, pq.second.y}});
+    const size_t n = ps.size();
+    Fp12 f = Fp12::one();
+    std::vector<Fp2> num(n), den(n), pre(n);
+    auto slopes = [&]() {      // num[k] / den[k] -> num[k] (den == 0 cannot occur for points of order r; it would give slope 0 and a rejected proof)
+        Fp2 run = Fp2::one(); for (size_t k = 0; k < n; k++) { pre[k] = run; run = run * den[k]; }
+        Fp2 inv = run.inv();
+        for (size_t k = n; k-- > 0;) { num[k] = num[k] * (inv * pre[k]); inv = inv * den[k]; }
+    };
+    auto apply = [&](size_t k, const Tw& other, bool dbl) {      // line through T (and `other`), then T <- T + other (or 2 T)
+        Tw& T = ps[k].T; const Fp2& lam = num[k];
+        f = f * line(lam, T, ps[k].P);
+        const Fp2 x3 = lam.sq() - T.x - (dbl ? T.x : other.x);
+        T = {x3, lam * (T.x - x3) - T.y};
+    };
+    auto dbl_all = [&]() { for (size_t k = 0; k < n; k++) { const Fp2 x2 = ps[k].T.x.sq(); num[k] = x2 + x2 + x2; den[k] = ps[k].T.y + ps[k].T.y; } slopes(); for (size_t k = 0; k < n; k++) apply(k, ps[k].T, true); };
+    auto add_all = [&](const std::vector<Tw>& o) { for (size_t k = 0; k < n; k++) { num[k] = o[k].y - ps[k].T.y; den[k] = o[k].x - ps[k].T.x; } slopes(); for (size_t k = 0; k < n; k++) apply(k, o[k], false); };
+    if (n) {
+        const u64 loop[2] = {0x9d797039be763ba8ull, 1};     // 6x + 2, x = 4965661367192848881
+        std::vector<Tw> q0(n), q1(n), q2(n);
+        for (size_t k = 0; k < n; k++) {
+            q0[k] = ps[k].Q;
+            q1[k] = {q0[k].x.conj() * K().g2, q0[k].y.conj() * K().g3};
+            q2[k] = {q1[k].x.conj() * K().g2, (q1[k].y.conj() * K().g3).neg()};
+        }
+        for (int i = 63; i >= 0; i--) { f = f.sq(); dbl_all(); if ((loop[i / 64] >> (i % 64)) & 1) add_all(q0); }
+        add_all(q1); add_all(q2);
+    }
+    const Fp12 easy1 = f.conj6() * f.inv();
+    const Fp12 g = easy1.frob2() * easy1, gi = g.conj6();
+    const auto& e = K().hard_naf; Fp12 r = Fp12::one();
+    for (size_t i = e.size(); i-- > 0;) { r = r.sq(); if (e[i] > 0) r = r * g; else if (e[i] < 0) r = r * gi; }
     return r.is_one();
 }
 
