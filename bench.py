@@ -336,7 +336,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("GSC_BENCH_BATCH", "0")), help="proofs per GPU per step (default 8192 ChaCha, 1024 AES, 3072 mixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (default: all the process may run on)")
-    ap.add_argument("--verify", type=int, default=256, help="proofs of the LAST timed step checked with libverify.so after the clock stops (0 = none)")
+    ap.add_argument("--verify", type=int, default=1024, help="proofs of the LAST timed step checked with libverify.so after the clock stops (0 = none)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (rehearsal of the multi-GPU code path on a one-GPU box)")
     ap.add_argument("--in-library", action="store_true", help="ONE process drives all --gpus devices through the library's own replicas (GSC_DEVICES=0..N-1): "
                                                                "what a single FFI host (Go / node) would do; one call of N x batch statements per step")
