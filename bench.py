@@ -3,8 +3,9 @@
 
 Default (the driver's call): ChaCha20-V3 single 64-byte blocks, one batch of --batch independent statements per GPU per step.
 A "step" is one pass of the hot path (witness -> quotient NTTs -> MSMs -> proof assembly) over that batch.  The other BASELINE
-configs are selected with --workload {chacha20,aes128,aes256,mixed} and --batch {1,64,1024,8192}; every run prints the same
-JSON line (profiles/r02_bench_*.json hold one per config).
+configs are selected with --workload {chacha20,aes128,aes256,mixed} and --batch {1,64,1024,8192} (--callers: concurrent caller
+threads); every run prints the same JSON line (profiles/r03_bench_*.json hold one per config) and, after the clock stops, checks a
+sample of the LAST timed step's proofs with the product's verifier libverify.so ("verified": n; a rejection fails the run).
 
   * chacha20 / aes128 / aes256 go through gsc_prove_raw (the binary twin of Prove: no JSON on the timed path);
   * mixed sends a JSON array (statement i uses cipher i mod 3) through ProveBatch, all three algorithms resident on the device.
@@ -12,13 +13,16 @@ JSON line (profiles/r02_bench_*.json hold one per config).
 Independent proofs shard across ranks (one process per GPU, weak scaling); the only collective is the gather of the finished
 proofs to rank 0 (RCCL over xGMI).  `--gpus N` without RANK in the environment makes this process a launcher: it starts N rank
 processes BEFORE anything touches torch or HIP and relays rank 0's line; under `torch.distributed.run` each rank reads
-RANK / LOCAL_RANK / WORLD_SIZE and the world size must equal --gpus.
+RANK / LOCAL_RANK / WORLD_SIZE and the world size must equal --gpus.  `--gpus N --in-library` is the other multi-GPU path: ONE process,
+GSC_DEVICES=0..N-1, one call of N x batch statements per step split over the library's own engine replicas (what a Go / node host does).
 
 The line carries, besides the contract's keys:
-  "roofline"      : the dominant kernel (the Z-table MSM gather-accumulate of the slowest algorithm in the workload) priced against
-                    HBM peak with SURVEY.md §8(d)'s algorithmic bytes, timed live with HIP events on the kernel's own stream;
+  "roofline"      : the dominant kernel (the Z-table MSM gather-accumulate of the slowest algorithm in the workload; the resident witness
+                    kernel for calls of a handful of statements) priced against HBM peak with SURVEY.md §8(d)'s algorithmic bytes of the
+                    statements the launch proved, timed live with HIP events on the kernel's own stream;
   "msm_stage"     : the whole MSM stage in GB/s on §8(d)'s MSM bytes per proof;
-  "cpu_baseline"  : the CPU oracle (oracle/, a port — not gnark) timed on the host cores on a bounded sample of the same workload.
+  "cpu_baseline"  : the CPU oracle (oracle/, a port — not gnark) timed on the cores the job may use (CPU quota) on a bounded sample of the same workload;
+  "verified"      : proofs of the last timed step accepted by libverify.so under the matching verifying key.
 """
 import argparse
 import json
