@@ -33,8 +33,10 @@ const char* kAlgorithmNames[3] = {"chacha20", "aes-128-ctr", "aes-256-ctr"};   /
 
 // Micro-batching: concurrent single-proof Prove() callers (the reference is called from many goroutines / FFI threads:
 // libraries/core_test.go:44-111) are gathered into ONE device batch instead of running one 25 ms proof each, back to back.
-// A worker thread per algorithm drains the queue: everything that arrived while the previous batch was on the GPU, plus
-// whatever arrives within a short linger window (GSC_LINGER_US, default 300 us; skipped for a lone caller on an idle device), goes out together.
+// Worker threads — one per (device, lane) of the algorithm's engine — drain the queue: what arrived while the devices were busy, plus
+// whatever arrives within a short linger window (GSC_LINGER_US, default 300 us; skipped for a lone caller while a device is idle), is
+// shared out over the workers that have nothing on a device (csrc/dispatch.hpp: batcher_take) and every share goes out as one device batch
+// to the least-loaded engine replica.
 class Batcher {
   public:
     explicit Batcher(Algorithm* a) : algo_(a) {
