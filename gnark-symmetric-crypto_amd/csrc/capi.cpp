@@ -32,50 +32,39 @@ namespace {
 const char* kAlgorithmNames[3] = {"chacha20", "aes-128-ctr", "aes-256-ctr"};   // prove_impl.go:21-25
 
 // Micro-batching: concurrent single-proof Prove() callers (the reference is called from many goroutines / FFI threads:
-// libraries/core_test.go:44-111) are gathered into ONE device batch instead of running one 25 ms proof each, back to back.
-// Worker threads — one per (device, lane) of the algorithm's engine — drain the queue: what arrived while the devices were busy, plus
-// whatever arrives within a short linger window (GSC_LINGER_US, default 300 us; skipped for a lone caller while a device is idle), is
-// shared out over the workers that have nothing on a device (csrc/dispatch.hpp: batcher_take) and every share goes out as one device batch
-// to the least-loaded engine replica.
+// libraries/core_test.go:44-111) are gathered into ONE device batch instead of running one proof each, back to back.
+// Worker threads — one per (device, lane) of the algorithm's engine — drain the queue; WHEN a worker takes HOW MANY callers is
+// csrc/dispatch.hpp's BatchScheduler (tested on CPU with a stub engine): a lone caller on an idle device goes at once; while every
+// device has a batch on it the callers that arrive form the next one; the callers of a batch that has just completed are waited for
+// as long as they keep coming back (GSC_LINGER_US, default 300 us, sets the windows; 0 = never wait on an idle device); a burst is
+// shared out over the free devices and every share goes out as one device batch to the least-loaded engine replica.
 class Batcher {
   public:
-    explicit Batcher(Algorithm* a) : algo_(a) {
-        const char* e = getenv("GSC_LINGER_US"); linger_us_ = e && *e ? atoi(e) : 300;
-        // one worker per (device, lane) of the engine: while one device batch is in its latency-bound stages, the next one is already
-        // being gathered and proved on another lane (AES-V2 has two lanes by default, ChaCha20-V3 one) or on another GPU
-        // (GSC_DEVICES: prove_batch hands every small batch to the least-loaded replica)
+    explicit Batcher(Algorithm* a) : algo_(a), sched_(a->devices() ? a->devices() : 1, a->max_batch(), linger_from_env()) {
+        // one worker per (device, lane): a second batch per device is started when enough callers are queued for it (dispatch.hpp)
         const size_t nw = (a->lanes() ? a->lanes() : 1) * (a->devices() ? a->devices() : 1);
         for (size_t i = 0; i < nw; i++) workers_.emplace_back([this] { run(); });
     }
-    ~Batcher() { { std::lock_guard<std::mutex> l(mu_); stop_ = true; } cv_.notify_all(); for (auto& w : workers_) if (w.joinable()) w.join(); }
+    ~Batcher() { { std::lock_guard<std::mutex> l(mu_); stop_ = true; } sched_.cv.notify_all(); for (auto& w : workers_) if (w.joinable()) w.join(); }
     // blocks until the proof is done; throws std::runtime_error if the device batch failed
     void submit(const ProofRequest& req, ProofResult& out) {
         Item it{&req, &out, false, std::string()};
-        { std::unique_lock<std::mutex> l(mu_); q_.push_back(&it); cv_.notify_all(); done_cv_.wait(l, [&] { return it.done; }); }
+        { std::unique_lock<std::mutex> l(mu_); q_.push_back(&it); sched_.arrived(); done_cv_.wait(l, [&] { return it.done; }); }
         if (!it.error.empty()) throw std::runtime_error(it.error);
     }
   private:
     struct Item { const ProofRequest* req; ProofResult* res; bool done; std::string error; };
+    static int linger_from_env() { const char* e = getenv("GSC_LINGER_US"); return e && *e ? atoi(e) : 300; }
     void run() {
         for (;;) {
             std::vector<Item*> take;
             {
                 std::unique_lock<std::mutex> l(mu_);
-                idle_++;
-                cv_.wait(l, [&] { return stop_ || !q_.empty(); });
-                if (stop_ && q_.empty()) return;
-                // linger only when it can pay: a burst is arriving (more than one caller queued) or every device has a batch of this algorithm on it
-                // anyway — a lone caller on an idle device goes at once (a single Prove takes 2.7 ms: 0.3 ms of waiting would be 11 % of it)
-                if (linger_us_ > 0 && (q_.size() > 1 || in_flight_ >= (int)algo_->devices()) && q_.size() < algo_->max_batch())
-                    cv_.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return stop_ || q_.size() >= algo_->max_batch(); });
-                // the queue is shared out over the workers that have nothing on a device (this one included): a burst of callers
-                // spreads over every replica and lane; a worker that is alone takes everything (dispatch.hpp)
-                const size_t want = batcher_take(q_.size(), (size_t)idle_, algo_->max_batch());
-                idle_--;
+                const size_t want = sched_.wait_for_batch(l, [&] { return q_.size(); }, stop_);
+                if (!want) return;                         // stopped, nothing queued
                 while (!q_.empty() && take.size() < want) { take.push_back(q_.front()); q_.pop_front(); }
-                if (!take.empty()) in_flight_++;
+                sched_.started(take.size());
             }
-            if (take.empty()) continue;                    // another worker took them while this one lingered
             std::vector<ProofRequest> reqs(take.size()); std::vector<ProofResult> res(take.size());
             for (size_t i = 0; i < take.size(); i++) reqs[i] = *take[i]->req;
             std::string err;
@@ -83,13 +72,13 @@ class Batcher {
             {
                 std::lock_guard<std::mutex> l(mu_);
                 for (size_t i = 0; i < take.size(); i++) { *take[i]->res = res[i]; take[i]->error = err; take[i]->done = true; }
-                in_flight_--;
+                sched_.completed(take.size());
             }
             done_cv_.notify_all();
         }
     }
-    Algorithm* algo_; int linger_us_ = 300; int in_flight_ = 0, idle_ = 0; bool stop_ = false;
-    std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Item*> q_; std::vector<std::thread> workers_;
+    Algorithm* algo_; BatchScheduler sched_; bool stop_ = false;
+    std::mutex mu_; std::condition_variable done_cv_; std::deque<Item*> q_; std::vector<std::thread> workers_;
 };
 
 std::mutex g_mu;

@@ -1,11 +1,13 @@
-// Which engine replica (one per device of GSC_DEVICES) serves a call, and how many queued single-proof callers a batcher worker
-// takes at a time.  Host-only policy code with no HIP in it: tests/test_dispatch_policy.py compiles it with g++ against a stub
+// Which engine replica (one per device of GSC_DEVICES) serves a call, and when a batcher worker takes how many of the queued
+// single-proof callers.  Host-only policy code with no HIP in it: tests/test_dispatch_policy.py compiles it with g++ against a stub
 // engine and checks the spread on CPU; engine.hip (Algorithm::prove_batch) and capi.cpp (Batcher) are the users.
 //
 // The reference's unit of work is ONE statement per Prove call, from any number of concurrent FFI threads
 // (libraries/prover/libprove.go:30-47; concurrent callers: libraries/core_test.go:44-111), so small calls must reach every GPU of the
 // node, not only the first one.
 #pragma once
+#include <chrono>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
 #include <mutex>
@@ -40,15 +42,91 @@ class ReplicaPicker {
     std::vector<Counters> served_;
 };
 
-// How many of `queued` single-proof callers a batcher worker takes when `idle_workers` workers (this one included) have nothing on a
-// device: the queue is shared out over the idle workers, so that a burst of callers spreads over every replica and lane instead of
-// riding one device batch; a worker that is alone takes everything (one big batch is the most efficient use of a busy node).
-inline size_t batcher_take(size_t queued, size_t idle_workers, size_t max_batch) {
+// How many of `queued` single-proof callers a batcher worker takes when `free_devices` devices (at least one) have no batch of the
+// algorithm on them: the queue is shared out over the free devices, so that a burst of callers spreads over every replica; on one
+// device everything goes out as ONE batch (the device time per statement falls with the batch: 2.65 ms for one, 0.40 ms at 16,
+// 0.20 ms at 64, 0.08 ms at 256 — two overlapped small batches never beat one of twice the size).
+inline size_t batcher_take(size_t queued, size_t free_devices, size_t max_batch) {
     if (!queued) return 0;
-    if (idle_workers < 1) idle_workers = 1;
-    size_t n = (queued + idle_workers - 1) / idle_workers;
+    if (free_devices < 1) free_devices = 1;
+    size_t n = (queued + free_devices - 1) / free_devices;
     if (n > max_batch) n = max_batch;
     return n ? n : 1;
 }
+
+// When a batcher worker takes a batch.  Concurrent single-statement callers (libraries/core_test.go:44-111: one Prove per goroutine,
+// the next one when the previous has returned) are a closed loop: the callers of a batch that has just completed come back within
+// microseconds, and whatever is taken while they are on their way rides a smaller, dearer batch.  Rules, with the queue lock held:
+//   * a full lane (queued >= max_batch) goes at once;
+//   * every device has a batch of this algorithm on it: wait for a completion (the callers that queue meanwhile form the next batch) —
+//     unless the queue holds at least SECOND_BATCH_MIN callers and at least as many as the batch started last: then a second batch
+//     per device is worth its overlap (lanes exist for that);
+//   * a device is free and a batch of k callers completed less than a moment ago: wait until k callers have arrived since, for as long
+//     as they keep arriving (gap: linger / 2, in all at most RETURN_MAX_US) — a lone caller's own return satisfies k = 1 at once;
+//   * a device is free, several callers are queued and nothing is known about them (a burst out of nowhere): the classic linger window, once;
+//   * otherwise (a lone caller, an idle device): go.
+// linger_us = 0 switches both waits off; waiting for a busy device is scheduling, not lingering, and stays.
+// The class holds only the bookkeeping; the queue, its mutex and the items are the user's (capi.cpp Batcher, tests/native/dispatch_check.cpp).
+class BatchScheduler {
+  public:
+    using Clock = std::chrono::steady_clock;
+    static constexpr size_t SECOND_BATCH_MIN = 64;
+    static constexpr int RETURN_MAX_US = 2000;
+    BatchScheduler(size_t devices, size_t max_batch, int linger_us) : devices_(devices ? devices : 1), max_batch_(max_batch ? max_batch : 1), linger_us_(linger_us < 0 ? 0 : linger_us) {}
+    std::condition_variable cv;             // workers wait here; notified on every arrival, completion and stop
+    // caller side, lock held, after the item was queued
+    void arrived() {
+        events_++; arrivals_since_done_++;
+        const Clock::time_point now = Clock::now();
+        if (now < return_hard_) { return_soft_ = now + std::chrono::microseconds(gap_us()); if (return_soft_ > return_hard_) return_soft_ = return_hard_; }
+        cv.notify_all();
+    }
+    // worker side, lock held: blocks until this worker should take a batch; returns its size (0: `stop` was raised and the queue is empty)
+    template <class Queued>
+    size_t wait_for_batch(std::unique_lock<std::mutex>& l, Queued queued, const bool& stop) {
+        bool lingered = false;
+        for (;;) {
+            cv.wait(l, [&] { return stop || queued() != 0; });
+            if (queued() == 0) return 0;                                      // stop
+            const size_t q = queued();
+            if (q >= max_batch_ || stop) break;
+            if (in_flight_ >= devices_) {
+                if (in_flight_ < 2 * devices_ && q >= SECOND_BATCH_MIN && q >= last_started_) break;
+                const uint64_t seen = events_;
+                cv.wait(l, [&] { return stop || events_ != seen; });
+                continue;
+            }
+            if (linger_us_ > 0) {
+                const Clock::time_point now = Clock::now();
+                if (now < return_soft_ && arrivals_since_done_ < returning_) { cv.wait_until(l, return_soft_); continue; }      // re-evaluated on every arrival
+                if (q > 1 && !lingered && returning_known(now) == false) {
+                    lingered = true;
+                    cv.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return stop || queued() >= max_batch_; });
+                    continue;
+                }
+            }
+            break;
+        }
+        const size_t free_devices = in_flight_ < devices_ ? devices_ - in_flight_ : 1;
+        return batcher_take(queued(), free_devices, max_batch_);
+    }
+    void started(size_t n) { in_flight_++; last_started_ = n; }                 // lock held, the batch has left the queue
+    void completed(size_t n) {                                                 // lock held, before the callers are woken
+        if (in_flight_) in_flight_--;
+        events_++; returning_ = n; arrivals_since_done_ = 0;
+        const Clock::time_point now = Clock::now();
+        return_soft_ = now + std::chrono::microseconds(gap_us()); return_hard_ = now + std::chrono::microseconds(linger_us_ ? RETURN_MAX_US : 0);
+        if (return_soft_ > return_hard_) return_soft_ = return_hard_;
+        cv.notify_all();
+    }
+    size_t in_flight() const { return in_flight_; }
+  private:
+    int gap_us() const { return linger_us_ / 2; }
+    // the queued callers are (part of) a batch that completed a moment ago: they were waited for already
+    bool returning_known(Clock::time_point now) const { return now < return_hard_; }
+    size_t devices_, max_batch_; int linger_us_;
+    size_t in_flight_ = 0, last_started_ = 0, returning_ = 0, arrivals_since_done_ = 0; uint64_t events_ = 0;
+    Clock::time_point return_soft_{}, return_hard_{};
+};
 
 }  // namespace gsc

@@ -13,18 +13,20 @@ using namespace gsc;
 
 #define CHECK(c) do { if (!(c)) { printf("FAILED %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
 
-// the batcher's worker loop (capi.cpp Batcher::run) over a stub engine that "proves" by sleeping
+// capi.cpp's Batcher over a stub engine that "proves" by sleeping: the same BatchScheduler decides when a worker takes how many callers
 struct StubNode {
-    ReplicaPicker picker; size_t max_batch; std::mutex mu; std::condition_variable cv, done; std::deque<int*> q; int idle = 0; bool stop = false;
-    std::vector<std::thread> workers; std::vector<std::atomic<int>> batches_on;
-    StubNode(size_t replicas, size_t lanes, size_t cap) : picker(replicas), max_batch(cap), batches_on(replicas) {
+    ReplicaPicker picker; BatchScheduler sched; std::mutex mu; std::condition_variable done; std::deque<int*> q; bool stop = false;
+    std::vector<std::thread> workers; std::vector<std::atomic<int>> batches_on; std::vector<size_t> batch_sizes;      // batch_sizes: under mu
+    int fixed_us, per_statement_us;
+    StubNode(size_t replicas, size_t lanes, size_t cap, int linger_us = 300, int fixed = 1000, int per = 100)
+        : picker(replicas), sched(replicas, cap, linger_us), batches_on(replicas), fixed_us(fixed), per_statement_us(per) {
         for (size_t i = 0; i < replicas * lanes; i++) workers.emplace_back([this] { run(); });
     }
-    ~StubNode() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); for (auto& w : workers) w.join(); }
+    ~StubNode() { { std::lock_guard<std::mutex> l(mu); stop = true; } sched.cv.notify_all(); for (auto& w : workers) w.join(); }
     void prove_batch(size_t n) {            // Algorithm::prove_batch for a call that is not split
         const size_t r = picker.acquire(n);
         batches_on[r]++;
-        std::this_thread::sleep_for(std::chrono::microseconds(1000 + 100 * n));      // a device batch: a fixed cost plus a share per statement
+        std::this_thread::sleep_for(std::chrono::microseconds(fixed_us + per_statement_us * (int)n));      // a device batch: a fixed cost plus a share per statement
         picker.release(r, n);
     }
     void run() {
@@ -32,20 +34,17 @@ struct StubNode {
             std::vector<int*> take;
             {
                 std::unique_lock<std::mutex> l(mu);
-                idle++;
-                cv.wait(l, [&] { return stop || !q.empty(); });
-                if (stop && q.empty()) return;
-                const size_t want = batcher_take(q.size(), (size_t)idle, max_batch);
-                idle--;
+                const size_t want = sched.wait_for_batch(l, [&] { return q.size(); }, stop);
+                if (!want) return;
                 while (!q.empty() && take.size() < want) { take.push_back(q.front()); q.pop_front(); }
+                sched.started(take.size()); batch_sizes.push_back(take.size());
             }
-            if (take.empty()) continue;
             prove_batch(take.size());
-            { std::lock_guard<std::mutex> l(mu); for (int* d : take) *d = 1; }
+            { std::lock_guard<std::mutex> l(mu); for (int* d : take) *d = 1; sched.completed(take.size()); }
             done.notify_all();
         }
     }
-    void submit() { int flag = 0; std::unique_lock<std::mutex> l(mu); q.push_back(&flag); cv.notify_all(); done.wait(l, [&] { return flag != 0; }); }
+    void submit() { int flag = 0; std::unique_lock<std::mutex> l(mu); q.push_back(&flag); sched.arrived(); done.wait(l, [&] { return flag != 0; }); }
 };
 
 int main() {
@@ -88,6 +87,55 @@ int main() {
         for (auto& c : sv) { lo = c.statements < lo ? c.statements : lo; hi = c.statements > hi ? c.statements : hi; total += c.statements; }
         printf("eight replicas: statements min %llu max %llu total %llu\n", (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)total);
         CHECK(total == 48 * 20 && lo > 0 && hi <= 3 * lo + 8);
+    }
+    {   // closed loop on ONE device (libraries/core_test.go:44-111: every caller issues its next Prove when the previous one has returned):
+        // after the first round the callers of a completed batch are waited for and ride ONE batch again — not several small ones
+        StubNode node(1, 3, 1024, 300, 2000, 50);
+        const int C = 16, rounds = 12;
+        std::vector<std::thread> callers;
+        for (int i = 0; i < C; i++) callers.emplace_back([&] { for (int k = 0; k < rounds; k++) node.submit(); });
+        for (auto& t : callers) t.join();
+        size_t total = 0, full = 0;
+        for (size_t b : node.batch_sizes) { total += b; if (b >= (size_t)C - 2) full++; }
+        printf("closed loop, 16 callers: %zu batches for %zu statements, %zu of them with >= 14 callers\n", node.batch_sizes.size(), total, full);
+        CHECK(total == (size_t)C * rounds && node.batch_sizes.size() <= (size_t)rounds + 6 && full >= (size_t)rounds - 4);
+    }
+    {   // while the device is busy the callers that arrive wait and form ONE next batch
+        StubNode node(1, 3, 1024, 300, 20000, 0);
+        std::thread first([&] { node.submit(); });
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        std::vector<std::thread> callers;
+        for (int i = 0; i < 10; i++) { callers.emplace_back([&] { node.submit(); }); std::this_thread::sleep_for(std::chrono::microseconds(700)); }
+        first.join(); for (auto& t : callers) t.join();
+        printf("busy device: batches"); for (size_t b : node.batch_sizes) printf(" %zu", b); printf("\n");
+        CHECK(node.batch_sizes.size() == 2 && node.batch_sizes[0] == 1 && node.batch_sizes[1] == 10);
+    }
+    {   // ... unless enough of them are queued to be worth a second batch on another lane (64, and no fewer than the batch started last)
+        StubNode node(1, 3, 1024, 300, 30000, 0);
+        std::thread first([&] { node.submit(); });
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        std::vector<std::thread> callers;
+        for (int i = 0; i < 80; i++) callers.emplace_back([&] { node.submit(); });
+        first.join(); for (auto& t : callers) t.join();
+        size_t total = 0; for (size_t b : node.batch_sizes) total += b;
+        printf("busy device, 80 more callers: batches"); for (size_t b : node.batch_sizes) printf(" %zu", b); printf("\n");
+        CHECK(total == 81 && node.batch_sizes.size() >= 2 && node.batch_sizes.size() <= 3 && node.batch_sizes[1] >= 64);
+    }
+    {   // a lone caller on an idle device is not kept waiting: per call, the stub's 2 ms plus well under the linger window
+        StubNode node(1, 3, 1024, 300, 2000, 0);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 50; k++) node.submit();
+        const double per_call_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 50;
+        printf("lone caller: %.0f us per call (stub batch: 2000 us)\n", per_call_us);
+        CHECK(node.batch_sizes.size() == 50 && per_call_us < 2000 + 250);
+    }
+    {   // two callers in a closed loop pair up instead of alternating
+        StubNode node(1, 3, 1024, 300, 2000, 0);
+        std::thread a([&] { for (int k = 0; k < 30; k++) node.submit(); }), b([&] { for (int k = 0; k < 30; k++) node.submit(); });
+        a.join(); b.join();
+        size_t pairs = 0; for (size_t x : node.batch_sizes) pairs += x == 2;
+        printf("two callers: %zu batches, %zu pairs\n", node.batch_sizes.size(), pairs);
+        CHECK(pairs >= 24);
     }
     printf("DISPATCH-OK\n");
     return 0;
