@@ -16,7 +16,7 @@ EXE = os.path.join(ROOT, "build", "ffi_harness")
 @pytest.fixture(scope="module")
 def harness(gsc):
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-o", EXE, os.path.join(ROOT, "integration", "ffi_harness.c"), "-ldl"])
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-o", EXE, os.path.join(ROOT, "integration", "ffi_harness.c"), "-ldl", "-lpthread"])
     return EXE, gsc.LIB_PATH
 
 
