@@ -98,9 +98,9 @@ class BatchScheduler {
             }
             if (linger_us_ > 0) {
                 const Clock::time_point now = Clock::now();
-                if (now < return_soft_ && arrivals_since_done_ < returning_) { cv.wait_until(l, return_soft_); continue; }      // re-evaluated on every arrival
+                if (now < return_soft_ && arrivals_since_done_ < returning_) { timed_waits_++; cv.wait_until(l, return_soft_); continue; }      // re-evaluated on every arrival
                 if (q > 1 && !lingered && returning_known(now) == false) {
-                    lingered = true;
+                    lingered = true; timed_waits_++;
                     cv.wait_for(l, std::chrono::microseconds(linger_us_), [&] { return stop || queued() >= max_batch_; });
                     continue;
                 }
@@ -120,12 +120,13 @@ class BatchScheduler {
         cv.notify_all();
     }
     size_t in_flight() const { return in_flight_; }
+    uint64_t timed_waits() const { return timed_waits_; }     // how often a worker waited on an IDLE device (linger / returning callers): 0 for a lone caller
   private:
     int gap_us() const { return linger_us_ / 2; }
     // the queued callers are (part of) a batch that completed a moment ago: they were waited for already
     bool returning_known(Clock::time_point now) const { return now < return_hard_; }
     size_t devices_, max_batch_; int linger_us_;
-    size_t in_flight_ = 0, last_started_ = 0, returning_ = 0, arrivals_since_done_ = 0; uint64_t events_ = 0;
+    size_t in_flight_ = 0, last_started_ = 0, returning_ = 0, arrivals_since_done_ = 0; uint64_t events_ = 0, timed_waits_ = 0;
     Clock::time_point return_soft_{}, return_hard_{};
 };
 
