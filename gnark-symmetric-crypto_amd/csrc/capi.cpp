@@ -52,6 +52,19 @@ class Batcher {
         { std::unique_lock<std::mutex> l(mu_); q_.push_back(&it); sched_.arrived(); done_cv_.wait(l, [&] { return it.done; }); }
         if (!it.error.empty()) throw std::runtime_error(it.error);
     }
+    // A small call of several statements (ProveBatch / gsc_prove_raw with up to SMALL_CALL statements): its statements queue like single
+    // callers, so concurrent small calls share device batches whatever entry point they came through.
+    static constexpr size_t SMALL_CALL = 32;
+    void submit_many(const ProofRequest* reqs, size_t n, ProofResult* out) {
+        std::vector<Item> items(n);
+        {
+            std::unique_lock<std::mutex> l(mu_);
+            for (size_t i = 0; i < n; i++) { items[i] = Item{&reqs[i], &out[i], false, std::string()}; q_.push_back(&items[i]); }
+            sched_.arrived(n);
+            done_cv_.wait(l, [&] { for (const Item& it : items) if (!it.done) return false; return true; });
+        }
+        for (const Item& it : items) if (!it.error.empty()) throw std::runtime_error(it.error);
+    }
   private:
     struct Item { const ProofRequest* req; ProofResult* res; bool done; std::string error; };
     static int linger_from_env() { const char* e = getenv("GSC_LINGER_US"); return e && *e ? atoi(e) : 300; }
@@ -323,7 +336,9 @@ struct Prove_return ProveBatch(GoSlice params) {
                 for (size_t k = 0; k < ok.size(); k++) if (ok[k].cipher == c) { reqs.push_back(ok[k].req); idx.push_back(where[k]); }
                 if (reqs.empty()) return;
                 std::vector<ProofResult> res(reqs.size());
-                lookup(c)->prove_batch(reqs.data(), reqs.size(), res.data());
+                Batcher* b = reqs.size() <= Batcher::SMALL_CALL ? batcher(c) : nullptr;
+                if (b) b->submit_many(reqs.data(), reqs.size(), res.data());      // a small group shares device batches with concurrent callers
+                else lookup(c)->prove_batch(reqs.data(), reqs.size(), res.data());
                 for (size_t k = 0; k < reqs.size(); k++) results[idx[k]] = res[k].status ? std::string("{}") : success_json(res[k], reqs[k].ciphertext);
             } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
         };
@@ -361,7 +376,9 @@ long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t
             fill_randomness(q);
         }
         const auto t1 = std::chrono::steady_clock::now();
-        a->prove_batch(reqs.data(), n, res.data());
+        Batcher* b = n && n <= Batcher::SMALL_CALL ? batcher(cipher) : nullptr;
+        if (b) b->submit_many(reqs.data(), n, res.data());      // a small call shares device batches with concurrent callers
+        else a->prove_batch(reqs.data(), n, res.data());
         const auto t2 = std::chrono::steady_clock::now();
         if (trace) fprintf(stderr, "gsc_prove_raw: prepare %.2f ms, prove_batch %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
         long long good = 0;

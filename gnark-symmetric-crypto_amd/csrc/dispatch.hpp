@@ -75,8 +75,8 @@ class BatchScheduler {
     BatchScheduler(size_t devices, size_t max_batch, int linger_us) : devices_(devices ? devices : 1), max_batch_(max_batch ? max_batch : 1), linger_us_(linger_us < 0 ? 0 : linger_us) {}
     std::condition_variable cv;             // workers wait here; notified on every arrival, completion and stop
     // caller side, lock held, after the item was queued
-    void arrived() {
-        events_++; arrivals_since_done_++;
+    void arrived(size_t n = 1) {
+        events_++; arrivals_since_done_ += n;
         const Clock::time_point now = Clock::now();
         if (now < return_hard_) { return_soft_ = now + std::chrono::microseconds(gap_us()); if (return_soft_ > return_hard_) return_soft_ = return_hard_; }
         cv.notify_all();
