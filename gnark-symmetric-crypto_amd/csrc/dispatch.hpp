@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -60,7 +61,8 @@ inline size_t batcher_take(size_t queued, size_t free_devices, size_t max_batch)
 //   * a full lane (queued >= max_batch) goes at once;
 //   * every device has a batch of this algorithm on it: wait for a completion (the callers that queue meanwhile form the next batch) —
 //     unless the queue holds at least SECOND_BATCH_MIN callers and at least as many as the batch started last: then a second batch
-//     per device is worth its overlap (lanes exist for that);
+//     per device is worth its overlap (lanes exist for that) — or its oldest caller has waited BUSY_WAIT_MAX_US (a lone caller that
+//     arrives under a batch of a thousand is not held for all of it);
 //   * a device is free and a batch of k callers completed less than a moment ago: wait until k callers have arrived since, for as long
 //     as they keep arriving (gap: linger / 2, in all at most RETURN_MAX_US) — a lone caller's own return satisfies k = 1 at once;
 //   * a device is free, several callers are queued and nothing is known about them (a burst out of nowhere): the classic linger window, once;
@@ -72,12 +74,14 @@ class BatchScheduler {
     using Clock = std::chrono::steady_clock;
     static constexpr size_t SECOND_BATCH_MIN = 64;
     static constexpr int RETURN_MAX_US = 2000;
+    static constexpr int BUSY_WAIT_MAX_US = 20000;
     BatchScheduler(size_t devices, size_t max_batch, int linger_us) : devices_(devices ? devices : 1), max_batch_(max_batch ? max_batch : 1), linger_us_(linger_us < 0 ? 0 : linger_us) {}
     std::condition_variable cv;             // workers wait here; notified on every arrival, completion and stop
     // caller side, lock held, after the item was queued
     void arrived(size_t n = 1) {
         events_++; arrivals_since_done_ += n;
         const Clock::time_point now = Clock::now();
+        for (size_t i = 0; i < n; i++) queued_at_.push_back(now);
         if (now < return_hard_) { return_soft_ = now + std::chrono::microseconds(gap_us()); if (return_soft_ > return_hard_) return_soft_ = return_hard_; }
         cv.notify_all();
     }
@@ -91,7 +95,14 @@ class BatchScheduler {
             const size_t q = queued();
             if (q >= max_batch_ || stop) break;
             if (in_flight_ >= devices_) {
-                if (in_flight_ < 2 * devices_ && q >= SECOND_BATCH_MIN && q >= last_started_) break;
+                if (in_flight_ < 2 * devices_) {
+                    if (q >= SECOND_BATCH_MIN && q >= last_started_) break;
+                    const Clock::time_point limit = (queued_at_.empty() ? Clock::now() : queued_at_.front()) + std::chrono::microseconds(BUSY_WAIT_MAX_US);
+                    if (Clock::now() >= limit) break;
+                    const uint64_t seen = events_;
+                    cv.wait_until(l, limit, [&] { return stop || events_ != seen; });
+                    continue;
+                }
                 const uint64_t seen = events_;
                 cv.wait(l, [&] { return stop || events_ != seen; });
                 continue;
@@ -110,7 +121,10 @@ class BatchScheduler {
         const size_t free_devices = in_flight_ < devices_ ? devices_ - in_flight_ : 1;
         return batcher_take(queued(), free_devices, max_batch_);
     }
-    void started(size_t n) { in_flight_++; last_started_ = n; }                 // lock held, the batch has left the queue
+    void started(size_t n) {                                                   // lock held, the batch (the n oldest callers) has left the queue
+        in_flight_++; last_started_ = n;
+        for (size_t i = 0; i < n && !queued_at_.empty(); i++) queued_at_.pop_front();
+    }
     void completed(size_t n) {                                                 // lock held, before the callers are woken
         if (in_flight_) in_flight_--;
         events_++; returning_ = n; arrivals_since_done_ = 0;
@@ -128,6 +142,7 @@ class BatchScheduler {
     size_t devices_, max_batch_; int linger_us_;
     size_t in_flight_ = 0, last_started_ = 0, returning_ = 0, arrivals_since_done_ = 0; uint64_t events_ = 0, timed_waits_ = 0;
     Clock::time_point return_soft_{}, return_hard_{};
+    std::deque<Clock::time_point> queued_at_;      // arrival times of the callers still queued, oldest first
 };
 
 }  // namespace gsc

@@ -121,6 +121,18 @@ int main() {
         printf("busy device, 80 more callers: batches"); for (size_t b : node.batch_sizes) printf(" %zu", b); printf("\n");
         CHECK(total == 81 && node.batch_sizes.size() >= 2 && node.batch_sizes.size() <= 3 && node.batch_sizes[0] == 1 && node.batch_sizes[1] >= 64);
     }
+    {   // ... or the oldest of them has waited 20 ms: a caller that arrives under a long batch is not held for all of it
+        StubNode node(1, 3, 1024, 300, 400000, 0);
+        std::thread first([&] { node.submit(); });
+        for (;;) { { std::lock_guard<std::mutex> l(node.mu); if (node.sched.in_flight() == 1) break; } std::this_thread::sleep_for(std::chrono::microseconds(200)); }
+        const auto t0 = std::chrono::steady_clock::now();
+        double waited_ms = 0;
+        std::thread late([&] { node.submit(); waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); });
+        late.join();
+        first.join();
+        printf("late caller under a 400 ms batch: done after %.0f ms (20 ms of waiting + its own 400 ms batch; behind the first batch it would be 800)\n", waited_ms);
+        CHECK(node.batch_sizes.size() == 2 && node.batch_sizes[1] == 1 && waited_ms >= 400 + 15 && waited_ms < 400 + 250);
+    }
     {   // a lone caller on an idle device is not kept waiting: no worker ever waits on the idle device for it
         StubNode node(1, 3, 1024, 300, 2000, 0);
         const auto t0 = std::chrono::steady_clock::now();
