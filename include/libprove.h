@@ -48,7 +48,8 @@ extern struct Prove_return ProveBatch(GoSlice params);
 /* Binary batch entry used by bench.py / tests (no JSON on the timed path).
  * cipher: algorithm id.  inputs: n records of 112 bytes {key[32] (AES-128: first 16 used), nonce[12],
  * counter u32 little-endian, input[64]}.  proofs: n x 196 bytes, proof_lens: n (0 on failure),
- * ciphertexts: n x 64 bytes.  Returns the number of proofs produced, or -1 if the algorithm is not initialised. */
+ * ciphertexts: n x 64 bytes.  Returns the number of proofs produced, or -1 if the algorithm is not initialised.
+ * A call of up to 32 statements (here and in ProveBatch) shares device batches with concurrent callers, like single Prove calls do. */
 extern long long gsc_prove_raw(GoUint8 cipher, const uint8_t *inputs, size_t n, uint8_t *proofs, uint32_t *proof_lens, uint8_t *ciphertexts);
 
 /* Groth16 Setup for one of the reference's circuits (stands in for groth16.Setup, keygen.go:345,384,423; needed because the
