@@ -46,6 +46,8 @@ struct EngineConfig {
     int few_workgroups = 0;      // GSC_FEW_WGS: its grid (workgroups of 8 waves, one per CU, so all are resident); 0 = 128 for 1-2 statements, 256 beyond
     int few_z_gb = 12;           // GSC_FEW_Z_GB: HBM budget of the latency-path layout of the quotient bases (rows per (base, window) of 8-, 6- or 4-bit digits: 8.6 GB ChaCha20 at 8, 11.5 GB AES at 6); 0 = none, such calls run the Horner pass
     int few_wide = 1;            // GSC_FEW_WIDE: the wide wires of the wire sets (AES: ~6 k per set) also get (base, window) rows for the latency path (~7.5 GB per AES algorithm); 0 = such calls run the windowed kernel + Horner for them
+    int quotient_eval = 1;       // GSC_QUOTIENT_EVAL: batch calls take the quotient in evaluation form (k_quot_bases.hip: four transforms instead of six, the Z sum over the
+                                 // bases V_i plus a flat sum over the solver's c); 0 = coefficient form for every call (six transforms, the key's own Z bases)
     bool trace_host = false;     // GSC_TRACE_HOST: host-side timing lines on stderr (InitAlgorithm breakdown, per-chunk enqueue / wait / serialise)
     // diagnostics that change what the device does: honoured only when the test hooks were enabled at load time (test_hooks_enabled())
     bool solver_trace = false;   // GSC_SOLVER_TRACE: per-level clock stamps of the witness kernels

@@ -92,6 +92,10 @@ class AlgorithmImpl {
     DevBuf<int32_t> tw_fwd, tw_inv, qr; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n
     // MSM sets
     MsmSet<G1Aff> mA, mB1, mK, mZ, mZfew, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
+    // Evaluation-form quotient (k_quot_bases.hip, cfg.quotient_eval): mZ then holds the bases V_i (scalars: d on the zeta-coset, launch_compute_d)
+    // and mC the bases U_i of the constraint rows (scalars: the solver's c, laid out like a wire set from row_class_c); calls that take the
+    // latency layout mZfew keep the coefficient form (it holds the key's own Z).
+    bool quotient_eval = false; MsmSet<G1Aff> mC; std::vector<uint8_t> row_class_c;
     // batch buffers: one set per lane.  A lane = a HIP stream with its own witness / polynomial / partial-sum buffers; with more than
     // one full lane big batches are cut into chunks that the lanes prove concurrently.  Measured on MI355X: for FULL
     // batches two lanes do not beat one (the MSM kernels fill the chip; chaining the heavy phases so that only the witness stage
@@ -108,13 +112,13 @@ class AlgorithmImpl {
         DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync; DevBuf<GlvSplit> d_glv;
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
-        DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
+        DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_sumC, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
         DevBuf<uint4> d_digits_s2; DevBuf<uint8_t> d_gok_s2;                                        // side2's digits (its partial sums are the G2 buffers, which nothing else uses)
         DevBuf<uint4> d_digits_s; DevBuf<uint8_t> d_gok_s; DevBuf<G1Xyzz> d_part1c, d_part1d;      // the side stream's MSM scratch (A and B1 of a latency-path call)
         DevBuf<uint4> d_digits;                                                   // signed digits [window][octet][proof]
         // per-window sums [window][proof] and flat-part sums [proof], one pair per set: the Horner passes of several sets are deferred
         // and run as one launch (MsmHornerJobs), so their inputs must not share storage
-        static constexpr int NSETS = 7;      // A, B1, K, Z, Ped, PedSigma, Z (latency layout)
+        static constexpr int NSETS = 8;      // A, B1, K, Z, Ped, PedSigma, Z (latency layout), C (evaluation-form quotient)
         DevBuf<G1Xyzz> d_sj1[NSETS], d_flat1[NSETS]; DevBuf<G2Xyzz> d_sj2, d_flat2;
         MsmHornerJobs pending1{}, pending2{};
         DevBuf<uint8_t> d_gok;                                                    // bit-group verdicts [group][wave of 64 proofs]
@@ -159,7 +163,10 @@ class AlgorithmImpl {
     // NARROW_MAX_BITS bits (with the margin) -> flat rows of that length; the rest (r, s, the lookup argument's products and inverses)
     // are wide: a few of them become window octets of the flat part, many get the windowed kernel and a Horner pass.
     template <class AffT, class XyzzT, class Decomp>
-    void build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw, size_t point_bytes, const std::vector<uint32_t>& rows, int c, const char* what, Decomp decomp, bool uniform, int expand_cv = 0);
+    // classes: the predicted class per scalar row (default: row_class, the wires); zero_row: a scalar row that is always zero (padding slots; default:
+    // row n_wires + 3 of W); latency_layout: also build the (base, window) rows of the windowed part for calls with a handful of statements
+    void build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw, size_t point_bytes, const std::vector<uint32_t>& rows, int c, const char* what, Decomp decomp, bool uniform, int expand_cv = 0,
+                   const std::vector<uint8_t>* classes = nullptr, uint32_t zero_row = 0xFFFFFFFFu, bool latency_layout = true);
     // group tables are built in chunks so that the projective scratch stays below ~2 GiB
     void build_subset(const G1Aff* b, size_t ng, G1Aff* t, uint8_t* ok);
     void build_subset(const G2Aff* b, size_t ng, G2Aff* t, uint8_t* ok);
@@ -193,7 +200,7 @@ class AlgorithmImpl {
     template <class AffT, class XyzzT, class LF, class LFF, class LW, class LWF, class LR, class LRF>
     void run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
                  MsmHornerJobs& pending, LF launch_flat, LFF launch_flat_few, LW launch_win, LWF launch_win_few, LR launch_reduce, LRF launch_reduce_few);
-    int set_index(const MsmSet<G1Aff>& set) const { const MsmSet<G1Aff>* all[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew}; for (int k = 0; k < Lane::NSETS; k++) if (all[k] == &set) return k; return 0; }
+    int set_index(const MsmSet<G1Aff>& set) const { const MsmSet<G1Aff>* all[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew, &mC}; for (int k = 0; k < Lane::NSETS; k++) if (all[k] == &set) return k; return 0; }
     // side = true: on the lane's side stream with scratch buffers of its own (flat sets of calls with a handful of statements only)
     void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false, bool side = false);
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum, bool side = false);

@@ -259,12 +259,26 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         run_msm_g2(ln, mB2, ln.d_W.p, 1, B, ln.d_sumB2.p, true);
         HIP_CHECK(hipEventRecord(ln.ev_s2, ln.side2));
     }
-    // 2. quotient polynomial (h overwrites A, canonical, bit-reversed order)
+    // 2. quotient polynomial.  Coefficient form: h overwrites A, canonical, bit-reversed order (six transforms).  Evaluation form (batch calls,
+    // k_quot_bases.hip): d = A B on the zeta-coset overwrites A, natural order (four transforms); c stays where the solver wrote it.
     NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
     HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
-    HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, ln.n_real <= (size_t)cfg.few_max && cfg.few_path ? ln.n_real : 0));      // latency path: the statements' columns only
+    const bool few_call = ln.n_real <= (size_t)cfg.few_max && cfg.few_path;
+    const bool use_zfew = few_call && mZfew.nflat;                 // the latency layout holds the key's own Z: coefficient form
+    const bool eval = quotient_eval && !use_zfew;
+    if (eval) {
+        if (dbg) {      // the debug vector is h itself: the coefficient-form kernels on copies (they overwrite their inputs)
+            DevBuf<fe> ta(domain_n * B), tb(domain_n * B), tc(domain_n * B);
+            HIP_CHECK(hipMemcpyAsync(ta.p, ln.d_A.p, n_constraints * B * sizeof(fe), hipMemcpyDeviceToDevice, ln.stream));
+            HIP_CHECK(hipMemcpyAsync(tb.p, ln.d_B.p, n_constraints * B * sizeof(fe), hipMemcpyDeviceToDevice, ln.stream));
+            HIP_CHECK(hipMemcpyAsync(tc.p, ln.d_C.p, n_constraints * B * sizeof(fe), hipMemcpyDeviceToDevice, ln.stream));
+            HIP_CHECK(launch_compute_h(plan, ta.p, tb.p, tc.p, n_constraints, B, ln.stream, 0));
+            fetch_column(ln, ta.p, domain_n, B, 0, dbg->H);
+        }
+        HIP_CHECK(launch_compute_d(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0));
+    } else HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0));      // latency path: the statements' columns only
     HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
-    if (dbg) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
+    if (dbg && !eval) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
     // 3. MSMs.  A and B1 first: the two scalar multiplications of the assembly only need those two sums and run on a side stream
     // beside the remaining MSMs.
     if (!early_ab) {
@@ -283,7 +297,8 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     }
     HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
     run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
-    run_msm_g1(ln, ln.n_real <= (size_t)cfg.few_max && cfg.few_path && mZfew.nflat ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
+    if (eval) run_msm_g1(ln, mC, ln.d_C.p, 1, B, ln.d_sumC.p);                    // sum c_i U_i: the solver's c rows, laid out like a wire set
+    run_msm_g1(ln, use_zfew ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
     if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
     flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
     if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);
@@ -292,7 +307,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     // 4. assembly
     HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_fs, 0));
     if (early_b2) HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev_s2, 0));
-    launch_fin_combine(ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, ln.d_tmp.p, B, ln.d_out.p, ln.d_flags.p, ln.stream);
+    launch_fin_combine(ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, eval ? ln.d_sumC.p : nullptr, ln.d_tmp.p, B, ln.d_out.p, ln.d_flags.p, ln.stream);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
     std::vector<uint8_t> h_out(256 * B), h_flags(ln.d_flags.n); std::vector<uint32_t> h_status(B);

@@ -115,8 +115,9 @@ void AlgorithmImpl::pack_inputs(const ProofRequest* reqs, size_t n, size_t B, st
 void AlgorithmImpl::calibrate() {
     row_class.assign(n_wires + 4, 255);
     row_class[n_wires] = row_class[n_wires + 1] = row_class[n_wires + 2] = 254;     // r, s, -rs: uniform scalars
+    row_class_c.assign(n_constraints, 255);                                         // the rows of c (evaluation-form quotient): same prediction, same fallbacks
     if (cfg.bit_groups <= 0) return;
-    if (cfg.bit_groups >= 2) { std::fill(row_class.begin(), row_class.begin() + n_wires, 0); return; }
+    if (cfg.bit_groups >= 2) { std::fill(row_class.begin(), row_class.begin() + n_wires, 0); std::fill(row_class_c.begin(), row_class_c.end(), 0); return; }
     const size_t B = 64;
     std::vector<ProofRequest> reqs(B);
     uint64_t x = 0x9E3779B97F4A7C15ull;
@@ -152,6 +153,10 @@ void AlgorithmImpl::calibrate() {
     launch_classify_wires(d_W.p, n_wires, B, d_status.p, d_cls.p, stream);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(row_class.data(), d_cls.p, n_wires, hipMemcpyDeviceToHost, stream));
+    DevBuf<uint8_t> d_cls_c(n_constraints);
+    launch_classify_wires(d_C.p, n_constraints, B, d_status.p, d_cls_c.p, stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(row_class_c.data(), d_cls_c.p, n_constraints, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
@@ -192,7 +197,9 @@ void AlgorithmImpl::build_rows(const AffT* bases, size_t n, const std::vector<ui
 }
 
 template <class AffT, class XyzzT, class Decomp>
-void AlgorithmImpl::build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw, size_t point_bytes, const std::vector<uint32_t>& rows, int c, const char* what, Decomp decomp, bool uniform, int expand_cv) {
+void AlgorithmImpl::build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw, size_t point_bytes, const std::vector<uint32_t>& rows, int c, const char* what, Decomp decomp, bool uniform, int expand_cv,
+                              const std::vector<uint8_t>* classes, uint32_t zero_row, bool latency_layout) {
+    const std::vector<uint8_t>& cls = classes ? *classes : row_class;
     const size_t n = raw.size() / point_bytes;
     if (rows.size() != n) throw std::runtime_error(std::string("pk: row map size mismatch for ") + what);
     set.nbases = n; set.c = c; set.nwin = msm_windows(c);
@@ -200,12 +207,12 @@ void AlgorithmImpl::build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw
     const std::vector<uint8_t> st = decomp(raw, bases.p);
     for (size_t i = 0; i < n; i++) if (st[i] == 1) throw std::runtime_error(std::string("pk: invalid point in ") + what);
     const size_t D = (size_t)1 << (c - 1);
-    const uint32_t ROW_ZERO = (uint32_t)(n_wires + 3);
+    const uint32_t ROW_ZERO = zero_row != 0xFFFFFFFFu ? zero_row : (uint32_t)(n_wires + 3);
     std::vector<uint32_t> bits, narrow, wide;            // indices into the key's order; the point at infinity contributes nothing: dropped
     std::vector<uint32_t> narrow_len;
     for (size_t i = 0; i < n; i++) {
         if (st[i] == 2) continue;
-        const int k = uniform || rows[i] >= row_class.size() ? 255 : row_class[rows[i]];
+        const int k = uniform || rows[i] >= cls.size() ? 255 : cls[rows[i]];
         if (uniform || cfg.bit_groups <= 0 || k == 255 || k + cfg.row_margin_bits > NARROW_MAX_BITS) wide.push_back((uint32_t)i);
         else if (k <= 1) bits.push_back((uint32_t)i);
         else { narrow.push_back((uint32_t)i); const int lb = k + cfg.row_margin_bits; narrow_len.push_back(1u << (lb < 0 ? 0 : lb)); }
@@ -265,11 +272,11 @@ void AlgorithmImpl::build_set(MsmSet<AffT>& set, const std::vector<uint8_t>& raw
         build_rows<AffT, XyzzT>(wb.p, set.nwide, off, len, set.wtable.p);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(stream));
-        if (!uniform && cfg.few_path && cfg.few_wide) {      // (the quotient bases have their own budgeted layout: init_key)
+        if (!uniform && cfg.few_path && cfg.few_wide && latency_layout) {      // (the quotient bases have their own budgeted layout: init_key)
             std::vector<uint8_t> raw_w(set.nwide * point_bytes); std::vector<uint32_t> rows_w(set.nwide);
             for (size_t i = 0; i < set.nwide; i++) { memcpy(raw_w.data() + i * point_bytes, raw.data() + (size_t)wide[i] * point_bytes, point_bytes); rows_w[i] = rows[wide[i]]; }
             set.few_wide.reset(new MsmSet<AffT>());
-            build_set<AffT, XyzzT>(*set.few_wide, raw_w, point_bytes, rows_w, c, what, decomp, true, 8);
+            build_set<AffT, XyzzT>(*set.few_wide, raw_w, point_bytes, rows_w, c, what, decomp, true, 8, classes, zero_row);
         }
     }
 }
@@ -324,7 +331,11 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
     std::vector<uint32_t> rowsB2 = rowsB;
     rowsB.push_back(ROW_ONE); rowsB.push_back(ROW_S); rowsB2.push_back(ROW_ONE); rowsB2.push_back(ROW_S);
     rowsK.push_back(ROW_NRS);
-    std::vector<uint32_t> rowsZ(domain_n - 1); for (size_t i = 0; i < rowsZ.size(); i++) rowsZ[i] = (uint32_t)i;
+    quotient_eval = cfg.quotient_eval != 0;
+    // coefficient form: the n - 1 bases of the key, scalars h; evaluation form: the n bases V_i, scalars d (k_quot_bases.hip)
+    std::vector<uint32_t> rowsZ(quotient_eval ? domain_n : domain_n - 1); for (size_t i = 0; i < rowsZ.size(); i++) rowsZ[i] = (uint32_t)i;
+    std::vector<uint32_t> rowsZkey(domain_n - 1); for (size_t i = 0; i < rowsZkey.size(); i++) rowsZkey[i] = (uint32_t)i;
+    std::vector<uint32_t> rowsC; if (quotient_eval) { rowsC.resize(n_constraints); for (size_t i = 0; i < n_constraints; i++) rowsC[i] = (uint32_t)i; }
     // Digit widths: explicit (GSC_WINDOW_Z / GSC_WINDOW_W) or the largest that keeps the tables inside the per-algorithm HBM
     // budget (the defaults leave room for all three algorithms of the reference on one 288 GB device: 3 x (48 + 16) GB).
     // Z: uniform rows of 2^(c-1) entries of 64 B: c = 16 is 69 GB for ChaCha20-V3 (2^15 - 1 bases), c = 14 is 69 GB for AES-V2 (2^17 - 1)
@@ -345,12 +356,13 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
         for (int c = MSM_MAX_WINDOW; c >= 4; c--) if ((double)rowsZ.size() * (double)((size_t)1 << (c - 1)) * 64.0 <= budget) { cfg.window_z = c; break; }
     }
     if (!cfg.window_w) {      // wire sets: only the wide wires that get the windowed kernel (more than EXPAND_MAX per set) pay for c
-        auto wide_of = [&](const std::vector<uint32_t>& rows) {
+        auto wide_in = [&](const std::vector<uint32_t>& rows, const std::vector<uint8_t>& cls) {
             size_t k = 0;
-            for (uint32_t r : rows) { const int cl = r < row_class.size() ? row_class[r] : 255; if (cfg.bit_groups <= 0 || cl == 255 || cl + cfg.row_margin_bits > NARROW_MAX_BITS) k++; }
+            for (uint32_t r : rows) { const int cl = r < cls.size() ? cls[r] : 255; if (cfg.bit_groups <= 0 || cl == 255 || cl + cfg.row_margin_bits > NARROW_MAX_BITS) k++; }
             return k > EXPAND_MAX ? (double)k : 0.0;
         };
-        const double g1 = wide_of(rowsA) + wide_of(rowsB) + wide_of(rowsK) + 2 * wide_of(cs.commit_private), g2 = wide_of(rowsB2);
+        auto wide_of = [&](const std::vector<uint32_t>& rows) { return wide_in(rows, row_class); };
+        const double g1 = wide_of(rowsA) + wide_of(rowsB) + wide_of(rowsK) + 2 * wide_of(cs.commit_private) + wide_in(rowsC, row_class_c), g2 = wide_of(rowsB2);
         cfg.window_w = 4;
         for (int c = 16; c >= 4; c--) if ((g1 * 64.0 + g2 * 128.0) * (double)((size_t)1 << (c - 1)) <= cfg.w_table_gb * 1e9) { cfg.window_w = c; break; }
     }
@@ -364,14 +376,44 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
     timed("G1.A", [&] { build_set<G1Aff, G1Xyzz>(mA, cat(key.g1_A, {&key.g1_alpha, &key.g1_delta}), 32, rowsA, cfg.window_w, "G1.A", dec1, false); });
     timed("G1.B", [&] { build_set<G1Aff, G1Xyzz>(mB1, cat(key.g1_B, {&key.g1_beta, &key.g1_delta}), 32, rowsB, cfg.window_w, "G1.B", dec1, false); });
     timed("G1.K", [&] { build_set<G1Aff, G1Xyzz>(mK, cat(key.g1_K, {&key.g1_delta}), 32, rowsK, cfg.window_w, "G1.K", dec1, false); });
-    timed("G1.Z", [&] { build_set<G1Aff, G1Xyzz>(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, true); });      // uniform full-width scalars
+    if (!quotient_eval) timed("G1.Z", [&] { build_set<G1Aff, G1Xyzz>(mZ, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, true); });      // uniform full-width scalars
+    else {
+        // The key's Z in evaluation form: U (scalars: the solver's c rows) and V (scalars: d on the zeta-coset), computed on the device from the
+        // decompressed points; build_set then lays them out like any other set — "decompression" is a device copy of the finished bases.
+        const size_t nz = key.g1_Z.size() / 32;
+        if (nz + 1 != domain_n) throw std::runtime_error("pk: G1.Z does not hold n - 1 points");
+        DevBuf<G1Aff> d_U(domain_n), d_V(domain_n); std::vector<uint8_t> stU(domain_n), stV(domain_n);
+        timed("G1.Z -> U, V", [&] {
+            DevBuf<G1Aff> zb(nz); const std::vector<uint8_t> st = decompress_g1(key.g1_Z, zb.p);
+            for (size_t i = 0; i < nz; i++) if (st[i] == 1) throw std::runtime_error("pk: invalid point in G1.Z");
+            DevBuf<uint8_t> d_st(nz), d_stU(domain_n), d_stV(domain_n); d_st.upload(st.data(), nz, stream);
+            DevBuf<fe> tw(domain_n / 2); DevBuf<G1Xyzz> scratch(domain_n);
+            launch_quot_bases(zb.p, d_st.p, L, 0, dom.p + 1, dom.p + 4, tw.p, scratch.p, d_U.p, d_stU.p, stream);
+            launch_quot_bases(zb.p, d_st.p, L, 1, dom.p + 1, dom.p + 4, tw.p, scratch.p, d_V.p, d_stV.p, stream);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(stU.data(), d_stU.p, domain_n, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(stV.data(), d_stV.p, domain_n, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+        });
+        auto from_dev = [this](const DevBuf<G1Aff>& src, const std::vector<uint8_t>& st) {
+            return [this, &src, &st](const std::vector<uint8_t>& raw, G1Aff* out) {
+                const size_t n = raw.size() / 32;
+                HIP_CHECK(hipMemcpyAsync(out, src.p, n * sizeof(G1Aff), hipMemcpyDeviceToDevice, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                return std::vector<uint8_t>(st.begin(), st.begin() + n);
+            };
+        };
+        const std::vector<uint8_t> rawV(domain_n * 32, 0), rawU(n_constraints * 32, 0);      // build_set only takes the point count from these
+        timed("G1.Z (V)", [&] { build_set<G1Aff, G1Xyzz>(mZ, rawV, 32, rowsZ, cfg.window_z, "G1.Z (evaluation form)", from_dev(d_V, stV), true); });
+        timed("G1.Z (U)", [&] { build_set<G1Aff, G1Xyzz>(mC, rawU, 32, rowsC, cfg.window_w, "G1.Z (evaluation form, c)", from_dev(d_U, stU), false, 0, &row_class_c, (uint32_t)domain_n, false); });
+    }
     if (cfg.few_path && cfg.few_z_gb > 0) {
         // calls with a handful of statements: the quotient bases once more as (base, window) pairs with their own rows 2^(cv j) d P — more
         // additions per proof than the wide rows above, but no 254-doubling Horner chain behind them (1.4 ms of a 6 ms Prove)
         const size_t nz = key.g1_Z.size() / 32;
         int cv = 0;
         for (int t : {8, 6, 4}) if ((double)nz * msm_windows(t) * (double)((size_t)1 << (t - 1)) * sizeof(G1Aff) <= (double)cfg.few_z_gb * 1e9) { cv = t; break; }
-        if (cv) timed("G1.Z (latency layout)", [&] { build_set<G1Aff, G1Xyzz>(mZfew, key.g1_Z, 32, rowsZ, cfg.window_z, "G1.Z", dec1, true, cv); });
+        if (cv) timed("G1.Z (latency layout)", [&] { build_set<G1Aff, G1Xyzz>(mZfew, key.g1_Z, 32, rowsZkey, cfg.window_z, "G1.Z", dec1, true, cv); });
     }
     timed("G2.B", [&] { build_set<G2Aff, G2Xyzz>(mB2, cat(key.g2_B, {&key.g2_beta, &key.g2_delta}), 64, rowsB2, cfg.window_w, "G2.B", dec2, false); });
     if (cs.has_commitment) {
@@ -389,13 +431,13 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
     ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2); ln.d_glv.alloc(2 * MSM_FEW_PROOFS);
-    ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc(domain_n * B);
+    ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc((domain_n + 1) * B);      // (+ one row that stays zero: the padding slots of mC)
     // calls with a handful of statements (k_solver_few) write their own columns only: the others must always hold field elements
     // (zero, later whatever an earlier call left there) because the transforms and MSMs run over whole 64-column batches
     HIP_CHECK(hipMemsetAsync(ln.d_W.p, 0, ln.d_W.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_A.p, 0, ln.d_A.n * sizeof(fe), ln.stream));
     HIP_CHECK(hipMemsetAsync(ln.d_B.p, 0, ln.d_B.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_C.p, 0, ln.d_C.n * sizeof(fe), ln.stream));
     // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
-    size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0, 0};
+    size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto need = [&](auto& m, size_t b, size_t& pa, size_t& pb, size_t& sj) {
         auto part = [&](size_t nb, size_t ns, size_t cols) {
             if (ns * cols > pa) pa = ns * cols;
@@ -410,7 +452,7 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
         }
         if (m.nwide) { const size_t bw = b * (size_t)m.nwin; part(m.nwide, msm_slices(m.nwide, (size_t)m.nwin, WIN_SLICE, b, per), bw); if (bw > sj) sj = bw; const size_t d = (size_t)m.nwin * ((m.nwide + 7) / 8) * b * msm_digit_words(m.c); if (d > dg) dg = d; }
     };
-    MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew};
+    MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew, &mC};
     for (size_t b = 64; b <= B; b += 64) {
         for (int k = 0; k < Lane::NSETS; k++) if (g1sets[k] != &mZfew || b == 64) need(*g1sets[k], b, p1, p1b, sj1[k]);      // the latency layout only serves 64-column batches
         need(mB2, b, p2, p2b, sj2);
@@ -432,7 +474,7 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     }
     for (int k = 0; k < Lane::NSETS; k++) { ln.d_sj1[k].alloc(sj1[k] ? sj1[k] : 1); ln.d_flat1[k].alloc(g1sets[k]->nflat && g1sets[k]->nwide ? B : 1); }
     ln.d_sj2.alloc(sj2 ? sj2 : 1); ln.d_flat2.alloc(B);
-    ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
+    ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumC.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
     if (has_commitment) { ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B); }
 }
 }  // namespace gsc

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64) void k_fin_scalarmul_few(const G1Xyzz* sumA, co
     }
     if (lane == 0) G1x::store_xyzz(reinterpret_cast<fe*>(tmp) + ((size_t)role * batch + p) * 4, acc);
 }
-__global__ __launch_bounds__(64) void k_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp,
+__global__ __launch_bounds__(64) void k_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* sumC, const G1Xyzz* tmp,
                                                      size_t batch, uint8_t* out, uint8_t* flags) {
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (p >= batch) return;
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(64) void k_fin_combine(const G2Xyzz* sumB2, const G
     if (role == 0) {
         const fe* K = reinterpret_cast<const fe*>(sumK); const fe* Z = reinterpret_cast<const fe*>(sumZ); const fe* T = reinterpret_cast<const fe*>(tmp);
         Xyzz9<Fp29f> v = G1x::add(G1x::add(G1x::load_xyzz(K + 4 * p), G1x::load_xyzz(Z + 4 * p)), G1x::add(G1x::load_xyzz(T + 4 * p), G1x::load_xyzz(T + 4 * (batch + p))));
+        if (sumC) v = G1x::add(v, G1x::load_xyzz(reinterpret_cast<const fe*>(sumC) + 4 * p));
         if (v.inf) fl |= 4;
         else { Aff9<Fp29f> A = G1x::to_aff(v); store_canon(out + 256 * p + 192, A.x); store_canon(out + 256 * p + 224, A.y); }
     } else {
@@ -346,8 +347,8 @@ void launch_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t
 void launch_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const GlvSplit* glv, size_t batch, size_t nproofs, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s) {
     hipLaunchKernelGGL(k_fin_scalarmul_few, dim3((unsigned)nproofs, 3), dim3(64), 0, s, sumA, sumB1, glv, batch, tmp, out, flags);      // roles: s * Ar, r * Bs1, Ar -> affine
 }
-void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s) {
-    hipLaunchKernelGGL(k_fin_combine, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumB2, sumK, sumZ, tmp, batch, out, flags);
+void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* sumC, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_fin_combine, dim3((unsigned)((batch + 63) / 64), 2), dim3(64), 0, s, sumB2, sumK, sumZ, sumC, tmp, batch, out, flags);
 }
 
 }  // namespace gsc

@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
 // K3: strided DIT tail for a and b; d = a*b on the zeta-coset; strided DIF head for d (written over a).  The last DIT stage and the
 // first DIF stage pair the same elements (e, e + G/2), so they stay in registers: each thread keeps two such pairs and folds
 // a, then b into one running value per element.
+// EVAL (evaluation-form quotient, k_quot_bases.hip): the kernel stops at d — d_i * 2^261 mod r as a canonical integer, natural order,
+// written over a — and the MSM takes it from there with the bases V_i; the inverse transform of d and the one of c are never run.
+template <bool EVAL>
 __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, size_t batch) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
@@ -284,6 +287,11 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
         last_dit(u4, lo0, hi0);
         last_dit(u4 + G / 4, lo1, hi1);
         __syncthreads();
+    }
+    if (EVAL) {
+        auto put_d = [&](uint32_t e, const fe9& v) { st_stream(va + (((size_t)e << Llo) + g) * batch + q0 + q, F::pack(F::freeze(v))); };
+        put_d(u4, lo0); put_d(u4 + G / 2, hi0); put_d(u4 + G / 4, lo1); put_d(u4 + G / 4 + G / 2, hi1);
+        return;
     }
     auto first_dif = [&](uint32_t e1, const fe9& lo, const fe9& hi) {       // first DIF stage (s = 0) on d: same pairs; twiddle exponent = gidx(e1) mod n/2
         const uint32_t e2 = e1 + G / 2;
@@ -334,7 +342,13 @@ __global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, co
 
 }  // namespace
 
-hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols) {
+namespace {
+hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, bool eval);
+}
+hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols) { return launch_quotient(p, a, b, c, m, batch, s, ncols, false); }
+hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols) { return launch_quotient(p, a, b, nullptr, m, batch, s, ncols, true); }
+namespace {
+hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, bool eval) {
     const int L = p.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     if (L < NTT_MIN_LOG2 || L > NTT_MAX_LOG2 || batch % P) return hipErrorInvalidValue;      // block sizes / launch bounds below assume this range
     const unsigned G = 1u << Lhi, Cn = 1u << Llo;
@@ -344,14 +358,17 @@ hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, siz
     hipError_t e = hipSuccess;
     auto opt_in = [&](const void* f, size_t lds) { if (e == hipSuccess && lds > 65536) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
     // 2^17 domains (AES-V2): 72 KiB tiles need the opt-in LDS limit (a CU has 160 KiB)
-    opt_in(reinterpret_cast<const void*>(k_ntt_dif_strided), lds_s); opt_in(reinterpret_cast<const void*>(k_ntt_pointwise_strided), lds_s);
+    opt_in(reinterpret_cast<const void*>(k_ntt_dif_strided), lds_s);
+    opt_in(eval ? reinterpret_cast<const void*>(k_ntt_pointwise_strided<true>) : reinterpret_cast<const void*>(k_ntt_pointwise_strided<false>), lds_s);
     opt_in(reinterpret_cast<const void*>(k_ntt_mid_contig), lds_c); opt_in(reinterpret_cast<const void*>(k_ntt_final_contig), lds_c);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch);
+    hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, eval ? 2 : 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch);
     hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 2), dim3(Cn / 4 * P), lds_c, s, p, a, b, c, batch);
-    hipLaunchKernelGGL(k_ntt_pointwise_strided, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch);
+    if (eval) { hipLaunchKernelGGL(k_ntt_pointwise_strided<true>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch); return hipGetLastError(); }
+    hipLaunchKernelGGL(k_ntt_pointwise_strided<false>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch);
     hipLaunchKernelGGL(k_ntt_final_contig, dim3(G, pb, 1), dim3(Cn / 4 * P), lds_c, s, p, a, c, batch);
     return hipGetLastError();
 }
+}  // namespace
 
 }  // namespace gsc

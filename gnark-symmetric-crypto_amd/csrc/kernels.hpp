@@ -95,6 +95,15 @@ constexpr int NTT_MIN_LOG2 = 15, NTT_MAX_LOG2 = 17;
 // Returns the first launch-configuration error (nothing is launched when the domain is unsupported).
 // ncols > 0: only the first ncols columns (rounded up to the tile's 4) are transformed — a call with a handful of statements in a 64-column batch
 hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols = 0);
+// The quotient in EVALUATION form: only the four transforms of a and b; on return a[i] = A(zeta w^i) B(zeta w^i) * 2^261 mod r as a
+// canonical integer, natural order (b overwritten, c not touched): the scalars of the bases V_i of launch_quot_bases.
+hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols = 0);
+// InitAlgorithm: the key's quotient bases in evaluation form (k_quot_bases.hip).  zfile: the n - 1 points of pk.G1.Z as stored
+// (bit-reversed order), zstatus[i] = 2 for a point at infinity; n = 2^L.  mode 0: out[i] = U_i = (1/2n) sum_k w^(-ik) Z_k (scalars: the
+// solver's c_i); mode 1: out[i] = V_i = -(1 / (2n 2^261)) sum_k zeta^(-k) w^(-ik) Z_k (scalars: launch_compute_d's output).  Natural order,
+// n points, affine (8 x 32-bit Montgomery images); status[i] = 2 for the point at infinity.  tw: n/2 elements, scratch: n points.
+void launch_quot_bases(const G1Aff* zfile, const uint8_t* zstatus, int L, int mode, const fe* omega_inv, const fe* n_inv,
+                       fe* tw, G1Xyzz* scratch, G1Aff* out, uint8_t* status, hipStream_t s);
 
 // ---- multi-scalar multiplication (k_msm_win.hip, k_msm.hip) ----
 // Every MSM of the prover is a fixed-base sum over a set of the proving key (A, B1, B2, K, Z, commitment bases) for a batch of
@@ -233,6 +242,7 @@ void launch_fin_scalarmul(const G1Xyzz* sumA, const G1Xyzz* sumB1, const uint8_t
 // the same for the first nproofs columns only, one wave per (statement, role): lanes share the doubling chain and split the two GLV
 // halves of the scalar (glv[2 * proof + role], role 0 = s, role 1 = r: glv.hpp glv_split on the host)
 void launch_fin_scalarmul_few(const G1Xyzz* sumA, const G1Xyzz* sumB1, const GlvSplit* glv, size_t batch, size_t nproofs, uint8_t* out, uint8_t* flags, G1Xyzz* tmp, hipStream_t s);
-void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s);
+// sumC: a further addend of Krs (the c-part of the evaluation-form quotient) or nullptr
+void launch_fin_combine(const G2Xyzz* sumB2, const G1Xyzz* sumK, const G1Xyzz* sumZ, const G1Xyzz* sumC, const G1Xyzz* tmp, size_t batch, uint8_t* out, uint8_t* flags, hipStream_t s);
 
 }  // namespace gsc
