@@ -107,7 +107,7 @@ def engine_env(workload, per_algo, share=1):
     env = {"GSC_MAX_BATCH": str(max(64, (per_algo + 63) // 64 * 64))}
     if workload != "mixed":      # one algorithm alone on the device: widest Z digits that fit (ChaCha c = 17: 137 GB; AES c = 15: 137 GB); mixed keeps the
         env["GSC_Z_TABLE_GB"] = str(140 // share)      # library defaults, under which all three algorithms are resident at once (3 x (48 + 16) GB)
-        env["GSC_W_TABLE_GB"] = str(48 // share)       # AES-V2 wide wires: c = 15 (42 GB) instead of 14
+        env["GSC_W_TABLE_GB"] = str(56 // share)       # AES-V2 wide wires (and the wide rows of c, evaluation-form quotient): c = 15 (48 GB) instead of 14
         # share > 1: several engine replicas on ONE device (the one-GPU rehearsal of --in-library --devices 0,0) split its memory
     return env
 

@@ -70,7 +70,7 @@ def test_usable_cores_is_bounded_by_the_affinity_mask():
 
 def test_engine_env_of_the_timed_run():
     e = bench.engine_env("chacha20", 8192)
-    assert e == {"GSC_MAX_BATCH": "8192", "GSC_Z_TABLE_GB": "140", "GSC_W_TABLE_GB": "48"}
+    assert e == {"GSC_MAX_BATCH": "8192", "GSC_Z_TABLE_GB": "140", "GSC_W_TABLE_GB": "56"}
     assert bench.engine_env("mixed", 1024) == {"GSC_MAX_BATCH": "1024"}                    # library defaults: all three algorithms resident
     assert bench.engine_env("chacha20", 4096, share=2)["GSC_Z_TABLE_GB"] == "70"           # two replicas rehearsed on one device split its memory
     assert bench.engine_env("aes128", 1000)["GSC_MAX_BATCH"] == "1024"

@@ -34,14 +34,14 @@ g = gsc_loader.load()
 assert g.init_algorithm(0, bench.golden("pk.chacha20"), bench.golden("r1cs.chacha20"))
 d = g.describe(0)
 print("DESCRIBE", d)
-assert "window_z=17 " in d and "max_batch=8192 " in d and "lanes=1 " in d, d
+assert "window_z=17 " in d and "max_batch=8192 " in d and "lanes=1 " in d and "quotient=evaluation-form" in d, d
 n = 8192
 recs = bench.xoshiro_records(n, 0x7E57 << 20)
 g.set_deterministic_randomness(int(sys.argv[3]), int(sys.argv[4]), 0)
 ok, proofs, lens, cts = g.prove_raw(0, recs, n)
 assert ok == n and set(lens) == {164}, (ok, set(lens))
 name, ms, stmts, cols, nb = g.last_dominant_kernel(0)
-assert name.startswith("k_msm_win") and stmts == n and cols == n and nb == 32767, (name, stmts, cols, nb)
+assert name.startswith("k_msm_win") and stmts == n and cols == n and nb == 32768, (name, stmts, cols, nb)      # evaluation-form quotient: the n bases V_i
 open(sys.argv[2], "wb").write(recs + proofs + cts)
 print("CHILD-OK")
 """
@@ -93,7 +93,7 @@ algo, name = int(sys.argv[5]), sys.argv[6]
 assert g.init_algorithm(algo, open(sys.argv[7], "rb").read(), bench.golden("r1cs." + name))
 d = g.describe(algo)
 print("DESCRIBE", d)
-assert "window_z=15 " in d and "window_w=15 " in d and "max_batch=1024 " in d and "lanes=2 " in d, d
+assert "window_z=15 " in d and "window_w=15 " in d and "max_batch=1024 " in d and "lanes=2 " in d and "quotient=evaluation-form" in d, d
 n = 1024
 recs = bench.provable(bench.xoshiro_records(n, 0xAE5 << 20), name)
 g.set_deterministic_randomness(int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[3]) ^ 0x5555)
@@ -146,7 +146,7 @@ def test_bench_verifies_its_own_proofs_and_reports_it():
     line = _bench_line("--steps", "2", "--warmup", "1", "--batch", "256", "--verify", "64")
     assert line["verified"] == 64 and line["n_gpus"] == 1 and line["config"]["batch_per_gpu"] == 256
     rf = line["roofline"]
-    assert rf["proofs_per_launch"] == 256 and rf["kernel"].startswith("k_msm_win") and rf["algorithmic_bytes_per_launch"] == 256 * 32767 * 96
+    assert rf["proofs_per_launch"] == 256 and rf["kernel"].startswith("k_msm_win") and rf["algorithmic_bytes_per_launch"] == 256 * 32768 * 96
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and "traffic_source" in rf
 
 

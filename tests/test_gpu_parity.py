@@ -229,7 +229,10 @@ def test_engine_options_do_not_change_the_proofs():
     # GSC_DEVICES=0,0: two engine replicas (here both on the one device of the box), every batch split between them — the in-library
     # multi-GPU path of a single FFI host process.
     for extra in ({"GSC_LANES": "2"}, {"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_DEVICES": "0,0"}, {"GSC_WINDOW_Z": "11", "GSC_MIN_SPLIT": "512"},
-                  {"GSC_WINDOW_Z": "0", "GSC_Z_TABLE_GB": "1", "GSC_LINGER_US": "0"}, {"GSC_SMALL_LANES": "0"}):
+                  {"GSC_WINDOW_Z": "0", "GSC_Z_TABLE_GB": "1", "GSC_LINGER_US": "0"}, {"GSC_SMALL_LANES": "0"},
+                  # GSC_QUOTIENT_EVAL=0: the quotient in coefficient form (six transforms, the key's own Z bases) instead of the default evaluation
+                  # form (four transforms, the bases V_i and a flat sum over the solver's c rows: k_quot_bases.hip) — the same group element
+                  {"GSC_QUOTIENT_EVAL": "0"}, {"GSC_QUOTIENT_EVAL": "0", "GSC_BIT_GROUPS": "0"}):
         assert _digest(extra) == base, extra
 
 
@@ -238,7 +241,7 @@ def test_engine_options_do_not_change_the_proofs_aes(aes_keys):
     pk_path = os.path.join(ROOT, "build", "keys", "pk.aes128")
     assert os.path.exists(pk_path)
     base = _digest({}, 1, pk_path)
-    for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_ROW_MARGIN_BITS": "-6"}, {"GSC_WINDOW_W": "9"}):
+    for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_ROW_MARGIN_BITS": "-6"}, {"GSC_WINDOW_W": "9"}, {"GSC_QUOTIENT_EVAL": "0"}):
         assert _digest(extra, 1, pk_path) == base, extra
 
 
@@ -256,7 +259,8 @@ def test_latency_path_options_do_not_change_the_proofs(aes_keys, algo, counts):
         # quotient layout budgets: ChaCha20 8-bit rows (8.6 GB) and 6-bit ones (2.9 GB); AES 4-bit rows (4.3 GB: the session's own algorithms hold most of the device)
         z, z2 = ("12", "3") if algo == 0 else ("5", "5")
         for extra in ({"GSC_FEW_Z_GB": z, "GSC_FEW_WIDE": "1"}, {"GSC_FEW_Z_GB": "0"}, {"GSC_FEW_Z_GB": z, "GSC_FEW_WGS": "17"},
-                      {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": z2, "GSC_FEW_WIDE": "1"}, {"GSC_FEW_MAX": "2", "GSC_FEW_Z_GB": z2}):
+                      {"GSC_FEW_SOLVER": "0", "GSC_FEW_Z_GB": z2, "GSC_FEW_WIDE": "1"}, {"GSC_FEW_MAX": "2", "GSC_FEW_Z_GB": z2},
+                      {"GSC_FEW_Z_GB": "0", "GSC_QUOTIENT_EVAL": "0"}):      # (without the latency layout such calls take the batch form of the quotient: both forms)
             assert _digest(dict(small, TEST_STATEMENTS=n, **extra), algo, pk_path) == base, (n, extra)
 
 
