@@ -297,7 +297,11 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     }
     HIP_CHECK(hipEventRecord(ln.ev_fs, ln.side));
     run_msm_g1(ln, mK, ln.d_W.p, 1, B, ln.d_sumK.p);
-    if (eval) run_msm_g1(ln, mC, ln.d_C.p, 1, B, ln.d_sumC.p);                    // sum c_i U_i: the solver's c rows, laid out like a wire set
+    if (eval) {                                                                  // sum c_i U_i: the solver's c rows, laid out like a wire set
+        // the padding slots of mC read row n of c, which must be zero for THIS batch's row stride (an earlier, larger batch had other rows there)
+        HIP_CHECK(hipMemsetAsync(ln.d_C.p + domain_n * B, 0, B * sizeof(fe), ln.stream));
+        run_msm_g1(ln, mC, ln.d_C.p, 1, B, ln.d_sumC.p);
+    }
     run_msm_g1(ln, use_zfew ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
     if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
     flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch

@@ -307,6 +307,27 @@ def test_bench_size_batch_every_proof_verifies(gsc_chacha):
     assert not g.verify({"cipher": "chacha20", "proof": base64.b64encode(proofs[196 * k:196 * k + 164]).decode(), "publicSignals": base64.b64encode(wrong).decode()})
 
 
+def test_a_small_batch_after_a_larger_one_on_the_same_lane(gsc_chacha, oracle, chacha_oracle):
+    # Batch buffers are [row][proof] with the batch as the row stride, so a batch of 64 columns finds the rows of an earlier, larger
+    # batch where its own rows end: whatever a kernel reads beyond the rows the solver wrote (the zero row behind c that pads the last
+    # octet of the evaluation-form quotient's c set) must be set for every batch.  200 statements, then 40, then 3 (latency path), then 40.
+    g = gsc_chacha; cs, pk, vk = chacha_oracle
+    rnd = random.Random(31337)
+    r, s = rnd.getrandbits(250), rnd.getrandbits(250)
+    g.set_deterministic_randomness(r, s, 0)
+    try:
+        for n in (200, 40, 3, 40):
+            recs = b"".join(rnd.randbytes(44) + rnd.getrandbits(32).to_bytes(4, "little") + rnd.randbytes(64) for _ in range(n))
+            ok, proofs, lens, cts = g.prove_raw(g.CHACHA20, recs, n)
+            assert ok == n and set(lens) == {164}
+            for k in (0, n - 1):
+                rec = recs[112 * k:112 * (k + 1)]
+                want, want_ct = oracle.prove(cs, pk, "chacha20", rec[:32], rec[32:44], int.from_bytes(rec[44:48], "little"), rec[48:], r, s)
+                assert cts[64 * k:64 * k + 64] == want_ct and proofs[196 * k:196 * k + 164] == want, (n, k)
+    finally:
+        g.set_deterministic_randomness(None)
+
+
 def test_repeated_batches_are_bit_identical(gsc_chacha):
     # No atomics, no data-dependent scheduling: with (r, s) fixed, proving the same 2048 statements again — alone or embedded in a
     # larger call that changes chunking and slice counts — must give the same bytes (catches races and uninitialised reads).
