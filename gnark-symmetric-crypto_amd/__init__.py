@@ -20,7 +20,7 @@ CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
 ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
 
 EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw", "gsc_setup",
-           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_dominant_kernel", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_glv_split"]
+           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_dominant_kernel", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_compute_d", "gsc_debug_glv_split"]
 
 
 class GoSlice(C.Structure):
@@ -251,6 +251,22 @@ def debug_compute_h(algorithm_id: int, abc_be: bytes, m: int) -> bytes:
     out = C.create_string_buffer(n * 64 * 32)
     if L.gsc_debug_compute_h(algorithm_id, abc_be, m, out, len(out)) != n:
         raise RuntimeError("gsc_debug_compute_h failed")
+    return out.raw
+
+
+def debug_compute_d(algorithm_id: int, ab_be: bytes, m: int) -> bytes:
+    """TEST HOOK: the evaluation-form quotient kernels on 64 columns of caller-supplied a|b ([m][64] big-endian each) ->
+    [domain][64] little-endian rows, row i = A(zeta w^i) B(zeta w^i) 2^261 mod r (raw bytes)."""
+    L = lib()
+    L.gsc_debug_compute_d.restype = C.c_longlong
+    L.gsc_debug_compute_d.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    n = L.gsc_debug_compute_d(algorithm_id, None, 0, None, 0)
+    if n <= 0:
+        raise RuntimeError("algorithm not initialised")
+    assert len(ab_be) == 2 * m * 64 * 32
+    out = C.create_string_buffer(n * 64 * 32)
+    if L.gsc_debug_compute_d(algorithm_id, ab_be, m, out, len(out)) != n:
+        raise RuntimeError("gsc_debug_compute_d failed")
     return out.raw
 
 

@@ -453,6 +453,15 @@ long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t* abc_be, size_t
     catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
 }
 
+long long gsc_debug_compute_d(GoUint8 algorithmID, const uint8_t* ab_be, size_t m, uint8_t* d_out, size_t cap) {
+    if (hooks_refused("gsc_debug_compute_d") || algorithmID > 2) return -1;
+    Algorithm* a = lookup(algorithmID); if (!a) return -1;
+    if (!d_out) return (long long)a->domain_size();
+    if (cap < a->domain_size() * 64 * 32) return -1;
+    try { a->debug_compute_d(ab_be, m, d_out); return (long long)a->domain_size(); }
+    catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
+}
+
 size_t gsc_describe(GoUint8 algorithmID, char* out, size_t cap) {
     if (algorithmID > 2 || !cap) return 0;
     Algorithm* a = lookup(algorithmID);

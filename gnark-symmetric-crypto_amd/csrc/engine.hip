@@ -127,6 +127,22 @@ void Algorithm::debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out)
     HIP_CHECK(hipMemcpyAsync(h_out, ln.d_A.p, a.domain_n * B * 32, hipMemcpyDeviceToHost, ln.stream));
     HIP_CHECK(hipStreamSynchronize(ln.stream));
 }
+void Algorithm::debug_compute_d(const uint8_t* ab_be, size_t m, uint8_t* d_out) {
+    AlgorithmImpl& a = *impls_[0];
+    if (m > a.n_constraints) throw std::runtime_error("debug_compute_d: more rows than constraints");
+    HIP_CHECK(hipSetDevice(a.cfg.device));
+    struct Hold { AlgorithmImpl& a; size_t i; ~Hold() { a.release_lane(i); } } hold{a, a.acquire_lane(0)};
+    AlgorithmImpl::Lane& ln = *a.lanes[0];
+    const size_t B = 64, cnt = m * B;
+    DevBuf<uint8_t> d_be(2 * cnt * 32 + 32);
+    d_be.upload(ab_be, 2 * cnt * 32, ln.stream);
+    launch_fr_from_be(d_be.p, ln.d_A.p, cnt, ln.stream);
+    launch_fr_from_be(d_be.p + cnt * 32, ln.d_B.p, cnt, ln.stream);
+    NttPlan plan{a.L, a.tw_fwd.p, a.tw_inv.p, a.scale_mid.p, a.scale_out.p, a.dom.p + 5, a.qr.p};
+    HIP_CHECK(launch_compute_d(plan, ln.d_A.p, ln.d_B.p, m, B, ln.stream));
+    HIP_CHECK(hipMemcpyAsync(d_out, ln.d_A.p, a.domain_n * B * 32, hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipStreamSynchronize(ln.stream));
+}
 // one replica: cut the request list into chunks (multiples of 64 proofs, at most one lane's capacity) and let worker threads pull
 // chunks, each on whichever lane is free.  A call with at least 2 * min_split statements that is alone on the replica is cut into as
 // many chunks as there are lanes (the latency-bound witness stage of one chunk hides under the kernels of the other); when other

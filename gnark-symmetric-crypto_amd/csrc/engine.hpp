@@ -87,6 +87,9 @@ class Algorithm {
     // 32-byte values (a, then b, then c; 64 independent columns), m <= number of constraints.  h_out: [domain][64] 32-byte
     // little-endian canonical values, row k = coefficient bitrev(k).
     void debug_compute_h(const uint8_t* abc_be, size_t m, uint8_t* h_out);
+    // TEST HOOK: the evaluation-form quotient kernels alone (launch_compute_d).  ab_be: a, then b, [m][64] canonical big-endian values.
+    // d_out: [domain][64] little-endian canonical values, row i = A(zeta w^i) B(zeta w^i) * 2^261 mod r (natural order).
+    void debug_compute_d(const uint8_t* ab_be, size_t m, uint8_t* d_out);
     size_t domain_size() const;
   private:
     std::vector<std::unique_ptr<AlgorithmImpl>> impls_;      // one per device

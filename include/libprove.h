@@ -87,6 +87,11 @@ extern int gsc_debug_field_ops(int field, int op, const uint8_t *a, const uint8_
  * h_out (cap bytes, at least domain*64*32): [domain][64] canonical little-endian values, row k = coefficient bitrev(k).
  * Returns the domain size (also when h_out is NULL: size query), -1 on error. */
 extern long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t *abc_be, size_t m, uint8_t *h_out, size_t cap);
+/* TEST HOOK: the quotient kernels of the EVALUATION form alone (what batch calls run: four transforms instead of six; see
+ * csrc/k_quot_bases.hip).  ab_be: a, then b, each [m][64] canonical big-endian values.  d_out: [domain][64] canonical little-endian
+ * values, row i = A(zeta w^i) * B(zeta w^i) * 2^261 mod r in natural order (zeta: the primitive 2n-th root of unity, w = zeta^2 the
+ * domain generator; A, B the interpolation polynomials of a, b).  Returns the domain size (also for d_out == NULL), -1 on error. */
+extern long long gsc_debug_compute_d(GoUint8 algorithmID, const uint8_t *ab_be, size_t m, uint8_t *d_out, size_t cap);
 /* TEST HOOK (host arithmetic only, no GPU): the GLV split the latency path feeds to its scalar multiplications
  * (csrc/glv.hpp).  k: canonical scalar < r, 32 bytes little-endian.  out: 20 bytes |k1|, 20 bytes |k2| (little-endian), 4 bytes
  * flags (bit 0: k1 < 0, bit 1: k2 < 0) with k = k1 + k2 * lambda (mod r).  Returns 0, -1 on error. */

@@ -79,3 +79,61 @@ def test_compute_h_aes_domain(gsc, oracle, aes_keys):
     assert gsc.init_algorithm(algo, pkb, r1cs)
     pk = oracle.ProvingKey(pkb)
     _check(gsc, oracle, pk, algo, 5000, 3, list(range(12)) + [40])
+
+
+# ---- the evaluation form (what batch calls run): d_i = A(zeta w^i) B(zeta w^i) on the coset, four transforms instead of six ----
+ROOT_2_28 = 0x2a3c09f0a58a7e8500e0a7eb8ef62abc402d111e41112ed49bd61b6e725b19f0      # gnark-crypto's 2^28-th root of unity of Fr
+
+
+def _intt(vals, w_inv, n):
+    """coefficients of the polynomial with the given values on 1, w, w^2, ... (plain radix-2, Python integers)"""
+    lg = n.bit_length() - 1
+    a = [vals[int(format(i, "0%db" % lg)[::-1], 2)] for i in range(n)]
+    half = 1
+    while half < n:
+        step = pow(w_inv, n // (2 * half), R)
+        for k in range(0, n, 2 * half):
+            t = 1
+            for j in range(k, k + half):
+                u, v = a[j], a[j + half] * t % R
+                a[j], a[j + half] = (u + v) % R, (u - v) % R
+                t = t * step % R
+        half *= 2
+    n_inv = pow(n, R - 2, R)
+    return [x * n_inv % R for x in a]
+
+
+def _check_d(g, oracle, pk, algo, m, seed, check_cols):
+    """The device's d against the oracle's computeH through H = (S - D) / 2: D = S - 2 H must be the polynomial whose values on the
+    coset zeta * w^i are the device's d_i (after taking out the 2^261 of the kernels' Montgomery domain)."""
+    x = _columns(m, seed)
+    raw = g.debug_compute_d(algo, x[:2].tobytes(), m)
+    n = pk.n
+    lg = n.bit_length() - 1
+    got = np.frombuffer(raw, dtype=np.uint8).reshape(n, 64, 32)
+    zeta = pow(ROOT_2_28, 1 << (27 - lg), R); w = zeta * zeta % R
+    assert pow(zeta, n, R) == R - 1
+    w_inv, zeta_inv, r261_inv = pow(w, R - 2, R), pow(zeta, R - 2, R), pow(pow(2, 261, R), R - 2, R)
+    for col in check_cols:
+        a, b, c = (np.ascontiguousarray(x[k, :, col]).tobytes() for k in range(3))
+        h = oracle.compute_h(pk, a, b, c)
+        H = [int.from_bytes(h[32 * k:32 * k + 32], "big") for k in range(n)]
+        cv = [int.from_bytes(c[32 * i:32 * i + 32], "big") for i in range(m)] + [0] * (n - m)
+        S = _intt(cv, w_inv, n)
+        d = [int.from_bytes(got[i, col].tobytes(), "little") for i in range(n)]
+        assert max(d) < R
+        E = _intt([v * r261_inv % R for v in d], w_inv, n)             # E_k = zeta^k D_k
+        zk = 1
+        for k in range(n):
+            assert E[k] * zk % R == (S[k] - 2 * H[k]) % R, "column %d coefficient %d" % (col, k)
+            zk = zk * zeta_inv % R
+
+
+def test_compute_d_chacha_domain_extreme_and_random_columns(gsc_chacha, oracle, chacha_oracle):
+    cs, pk, vk = chacha_oracle
+    _check_d(gsc_chacha, oracle, pk, gsc_chacha.CHACHA20, cs.n_constraints, 1, list(range(10)) + [10, 33, 63])
+
+
+def test_compute_d_short_vectors(gsc_chacha, oracle, chacha_oracle):
+    cs, pk, vk = chacha_oracle
+    _check_d(gsc_chacha, oracle, pk, gsc_chacha.CHACHA20, 777, 2, [1, 4, 7, 9, 17])

@@ -45,12 +45,13 @@ def test_test_hooks_refuse_without_the_environment_opt_in(gsc):
         "assert L.gsc_debug_field_ops(0, 0, one, one, C.create_string_buffer(32), 1, 1) == -1\n"
         "s, keep = g._slice(b'{}'); assert L.gsc_debug_prove(s) == -1\n"
         "L.gsc_debug_compute_h.restype = C.c_longlong; assert L.gsc_debug_compute_h(0, None, 0, None, 0) == -1\n"
+        "L.gsc_debug_compute_d.restype = C.c_longlong; assert L.gsc_debug_compute_d(0, None, 0, None, 0) == -1\n"
         "pk, vk, a, b = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()\n"
         "s2, keep2 = g._slice(b'x'); assert L.gsc_setup(s2, one, C.byref(pk), C.byref(a), C.byref(vk), C.byref(b)) == -1 and not pk.value\n"
         "try:\n    g.set_deterministic_randomness(1, 1)\nexcept RuntimeError: print('refused')\n" % ROOT)
     env = {k: v for k, v in os.environ.items() if k != "GSC_ENABLE_TEST_HOOKS"}
     out = subprocess.check_output([sys.executable, "-c", code], env=env).decode()
-    assert "refused\n" in out and out.count("test hooks are disabled") == 7      # (C stdio and Python flush in their own order)
+    assert "refused\n" in out and out.count("test hooks are disabled") == 8      # (C stdio and Python flush in their own order)
     assert gsc.lib().gsc_set_deterministic_randomness(None, None, None) == 0      # this process opted in (conftest.py)
 
 
