@@ -44,6 +44,7 @@ EngineConfig config_from_env() {
     c.few_z_gb = env_int("GSC_FEW_Z_GB", 12);
     c.few_wide = env_int("GSC_FEW_WIDE", 1);
     c.quotient_eval = env_int("GSC_QUOTIENT_EVAL", 1);
+    c.fuse_z_digits = env_int("GSC_FUSE_Z_DIGITS", 1);
     if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");
     c.trace_host = getenv("GSC_TRACE_HOST") != nullptr;
     if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; }
@@ -102,7 +103,7 @@ std::string Algorithm::describe() const {
              impl_->mA.nwide, impl_->mA.nexpanded, impl_->mB1.nwide, impl_->mB1.nexpanded, impl_->mK.nwide, impl_->mK.nexpanded);
     // per replica: calls and statements it has served (ReplicaPicker): shows that small calls reach every device
     std::string out = buf;
-    if (impl_->quotient_eval) out += " quotient=evaluation-form(c: " + std::to_string(impl_->mC.nbit) + " grouped + " + std::to_string(impl_->mC.nflat - impl_->mC.nbit) + " flat + " + std::to_string(impl_->mC.nwide) + " windowed)";
+    if (impl_->quotient_eval) out += std::string(" quotient=evaluation-form") + (impl_->fuse_z_digits ? "+digits" : "") + "(c: " + std::to_string(impl_->mC.nbit) + " grouped + " + std::to_string(impl_->mC.nflat - impl_->mC.nbit) + " flat + " + std::to_string(impl_->mC.nwide) + " windowed)";
     else out += " quotient=coefficient-form";
     out += " served(calls/statements)=";
     const auto sv = picker_->served();

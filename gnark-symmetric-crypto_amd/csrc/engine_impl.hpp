@@ -96,6 +96,9 @@ class AlgorithmImpl {
     // and mC the bases U_i of the constraint rows (scalars: the solver's c, laid out like a wire set from row_class_c); calls that take the
     // latency layout mZfew keep the coefficient form (it holds the key's own Z).
     bool quotient_eval = false; MsmSet<G1Aff> mC; std::vector<uint8_t> row_class_c;
+    // ... and the last quotient kernel writes the digits of d itself (launch_compute_d_digits): mZ's table positions follow quot_digit_index,
+    // whole batches skip the recoding pass and run the Z sum first (its digits sit in the lane's digit buffer until then)
+    bool fuse_z_digits = false;
     // batch buffers: one set per lane.  A lane = a HIP stream with its own witness / polynomial / partial-sum buffers; with more than
     // one full lane big batches are cut into chunks that the lanes prove concurrently.  Measured on MI355X: for FULL
     // batches two lanes do not beat one (the MSM kernels fill the chip; chaining the heavy phases so that only the witness stage
@@ -198,11 +201,12 @@ class AlgorithmImpl {
     // The Horner pass of the windowed part is NOT launched here: it is queued in `pending` and flushed together with those of other
     // sets (flush_horner_*), because each is a serial chain of 254 doublings whose duration does not depend on the batch.
     template <class AffT, class XyzzT, class LF, class LFF, class LW, class LWF, class LR, class LRF>
-    void run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
+    void run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed, bool digits_ready,
                  MsmHornerJobs& pending, LF launch_flat, LFF launch_flat_few, LW launch_win, LWF launch_win_few, LR launch_reduce, LRF launch_reduce_few);
     int set_index(const MsmSet<G1Aff>& set) const { const MsmSet<G1Aff>* all[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew, &mC}; for (int k = 0; k < Lane::NSETS; k++) if (all[k] == &set) return k; return 0; }
     // side = true: on the lane's side stream with scratch buffers of its own (flat sets of calls with a handful of statements only)
-    void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false, bool side = false);
+    // digits_ready: the windowed part's digits are already in the lane's digit buffer (fuse_z_digits): no recoding pass
+    void run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed = false, bool side = false, bool digits_ready = false);
     void run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum, bool side = false);
     void flush_horner_g1(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g1(ln.pending1, B, s); ln.pending1.n = 0; }
     void flush_horner_g2(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g2(ln.pending2, B, s); ln.pending2.n = 0; }

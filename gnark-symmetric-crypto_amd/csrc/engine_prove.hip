@@ -46,7 +46,7 @@ void AlgorithmImpl::reduce_slices_few(hipStream_t st, XyzzT* pa, XyzzT* pb, size
 }
 
 template <class AffT, class XyzzT, class LF, class LFF, class LW, class LWF, class LR, class LRF>
-void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed,
+void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set, const fe* scalars, bool wires, size_t B, size_t n_real, XyzzT* pa, XyzzT* pb, XyzzT* sj, XyzzT* flat, XyzzT* sum, bool timed, bool digits_ready,
              MsmHornerJobs& pending, LF launch_flat, LFF launch_flat_few, LW launch_win, LWF launch_win_few, LR launch_reduce, LRF launch_reduce_few) {
     size_t per = 0;
     const bool fewm = n_real <= (size_t)cfg.few_max && cfg.few_path;
@@ -97,7 +97,7 @@ void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set
         if (few && nslices > (set.nwide + 511) / 512) { per = 512; nslices = (set.nwide + 511) / 512; }
         const size_t Bw = B * (size_t)set.nwin;
         MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ctx.digits};
-        launch_msm_recode(ra, ctx.stream);
+        if (!digits_ready) launch_msm_recode(ra, ctx.stream);
         MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa};
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
         if (few) launch_win_few(a, n_real, ctx.stream);
@@ -111,20 +111,20 @@ void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set
     if (!set.nflat && !set.nwide) HIP_CHECK(hipMemsetAsync(sum, 0, B * sizeof(XyzzT), ctx.stream));      // empty set: the point at infinity
 }
 
-void AlgorithmImpl::run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed, bool side) {
+void AlgorithmImpl::run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* scalars, int mont, size_t B, G1Xyzz* sum, bool timed, bool side, bool digits_ready) {
     const int k = set_index(set);
     if (side) {
         if (!set.latency_flat() || B != 64) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
-        run_msm(ln, MsmCtx{ln.side, ln.d_digits_s.p, ln.d_gok_s.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1c.p, ln.d_part1d.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, false, ln.pending1,
+        run_msm(ln, MsmCtx{ln.side, ln.d_digits_s.p, ln.d_gok_s.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1c.p, ln.d_part1d.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, false, false, ln.pending1,
                 launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
         return;
     }
-    run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
+    run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, digits_ready, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
 }
 
 void AlgorithmImpl::run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum, bool side) {
     if (side && (!set.latency_flat() || B != 64)) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
-    run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_reduce_few_g2);
+    run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_reduce_few_g2);
 }
 
 void AlgorithmImpl::fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
@@ -275,11 +275,15 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
             HIP_CHECK(launch_compute_h(plan, ta.p, tb.p, tc.p, n_constraints, B, ln.stream, 0));
             fetch_column(ln, ta.p, domain_n, B, 0, dbg->H);
         }
-        HIP_CHECK(launch_compute_d(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0));
+        if (fuse_z_digits && !few_call) HIP_CHECK(launch_compute_d_digits(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, QuotDigits{ln.d_digits.p, mZ.c, mZ.nwin}, ln.stream));
+        else HIP_CHECK(launch_compute_d(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0));
     } else HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0));      // latency path: the statements' columns only
     HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
     if (dbg && !eval) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
-    // 3. MSMs.  A and B1 first: the two scalar multiplications of the assembly only need those two sums and run on a side stream
+    // 3. MSMs.  With the digits of d already in the lane's digit buffer (fuse_z_digits) the Z sum goes first: every other set recodes into that buffer.
+    const bool z_first = eval && fuse_z_digits && !few_call;
+    if (z_first) run_msm_g1(ln, mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call, false, true);
+    // A and B1 next: the two scalar multiplications of the assembly only need those two sums and run on a side stream
     // beside the remaining MSMs.
     if (!early_ab) {
         run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p);
@@ -302,7 +306,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         HIP_CHECK(hipMemsetAsync(ln.d_C.p + domain_n * B, 0, B * sizeof(fe), ln.stream));
         run_msm_g1(ln, mC, ln.d_C.p, 1, B, ln.d_sumC.p);
     }
-    run_msm_g1(ln, use_zfew ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
+    if (!z_first) run_msm_g1(ln, use_zfew ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
     if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
     flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
     if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);

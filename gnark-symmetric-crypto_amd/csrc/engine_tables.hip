@@ -333,7 +333,8 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
     rowsK.push_back(ROW_NRS);
     quotient_eval = cfg.quotient_eval != 0;
     // coefficient form: the n - 1 bases of the key, scalars h; evaluation form: the n bases V_i, scalars d (k_quot_bases.hip)
-    std::vector<uint32_t> rowsZ(quotient_eval ? domain_n : domain_n - 1); for (size_t i = 0; i < rowsZ.size(); i++) rowsZ[i] = (uint32_t)i;
+    // (evaluation form: table position t holds V of index quot_digit_index(L, t), the order in which the last quotient kernel's threads hold d)
+    std::vector<uint32_t> rowsZ(quotient_eval ? domain_n : domain_n - 1); for (size_t i = 0; i < rowsZ.size(); i++) rowsZ[i] = quotient_eval ? quot_digit_index(L, (uint32_t)i) : (uint32_t)i;
     std::vector<uint32_t> rowsZkey(domain_n - 1); for (size_t i = 0; i < rowsZkey.size(); i++) rowsZkey[i] = (uint32_t)i;
     std::vector<uint32_t> rowsC; if (quotient_eval) { rowsC.resize(n_constraints); for (size_t i = 0; i < n_constraints; i++) rowsC[i] = (uint32_t)i; }
     // Digit widths: explicit (GSC_WINDOW_Z / GSC_WINDOW_W) or the largest that keeps the tables inside the per-algorithm HBM
@@ -387,9 +388,10 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
             DevBuf<G1Aff> zb(nz); const std::vector<uint8_t> st = decompress_g1(key.g1_Z, zb.p);
             for (size_t i = 0; i < nz; i++) if (st[i] == 1) throw std::runtime_error("pk: invalid point in G1.Z");
             DevBuf<uint8_t> d_st(nz), d_stU(domain_n), d_stV(domain_n); d_st.upload(st.data(), nz, stream);
-            DevBuf<fe> tw(domain_n / 2); DevBuf<G1Xyzz> scratch(domain_n);
-            launch_quot_bases(zb.p, d_st.p, L, 0, dom.p + 1, dom.p + 4, tw.p, scratch.p, d_U.p, d_stU.p, stream);
-            launch_quot_bases(zb.p, d_st.p, L, 1, dom.p + 1, dom.p + 4, tw.p, scratch.p, d_V.p, d_stV.p, stream);
+            DevBuf<fe> tw(domain_n / 2); DevBuf<G1Xyzz> scratch(domain_n); DevBuf<uint32_t> d_perm(domain_n);
+            d_perm.upload(rowsZ.data(), domain_n, stream);
+            launch_quot_bases(zb.p, d_st.p, L, 0, dom.p + 1, dom.p + 4, tw.p, scratch.p, nullptr, d_U.p, d_stU.p, stream);
+            launch_quot_bases(zb.p, d_st.p, L, 1, dom.p + 1, dom.p + 4, tw.p, scratch.p, d_perm.p, d_V.p, d_stV.p, stream);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(stU.data(), d_stU.p, domain_n, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipMemcpyAsync(stV.data(), d_stV.p, domain_n, hipMemcpyDeviceToHost, stream));
@@ -405,6 +407,7 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
         };
         const std::vector<uint8_t> rawV(domain_n * 32, 0), rawU(n_constraints * 32, 0);      // build_set only takes the point count from these
         timed("G1.Z (V)", [&] { build_set<G1Aff, G1Xyzz>(mZ, rawV, 32, rowsZ, cfg.window_z, "G1.Z (evaluation form)", from_dev(d_V, stV), true); });
+        fuse_z_digits = mZ.nwide == domain_n && cfg.fuse_z_digits != 0;      // (a V_i at infinity would be dropped from the table: positions would shift)
         timed("G1.Z (U)", [&] { build_set<G1Aff, G1Xyzz>(mC, rawU, 32, rowsC, cfg.window_w, "G1.Z (evaluation form, c)", from_dev(d_U, stU), false, 0, &row_class_c, (uint32_t)domain_n, false); });
     }
     if (cfg.few_path && cfg.few_z_gb > 0) {

@@ -258,8 +258,12 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
 // a, then b into one running value per element.
 // EVAL (evaluation-form quotient, k_quot_bases.hip): the kernel stops at d — d_i * 2^261 mod r as a canonical integer, natural order,
 // written over a — and the MSM takes it from there with the bases V_i; the inverse transform of d and the one of c are never run.
-template <bool EVAL>
-__global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, size_t batch) {
+// EVAL == 2: d is not written either: the thread recodes its four values into the signed c-bit digits of the windowed MSM and writes those
+// (kernels.hpp QuotDigits; the recoding of k_msm_win.hip k_recode for canonical scalars): its elements u4 + {0, 1, 2, 3} * G/4 are the
+// bases 4 m .. 4 m + 3, m = g * G/4 + u4, i.e. one half of octet m / 2 — one 16-byte word of four int32 digits per window when c > 16, half
+// a word of int16 digits otherwise.
+template <int EVAL>
+__global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* va, const fe* vb, size_t batch, QuotDigits qd) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t G = 1u << Lhi;
@@ -288,9 +292,32 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
         last_dit(u4 + G / 4, lo1, hi1);
         __syncthreads();
     }
-    if (EVAL) {
+    if (EVAL == 1) {
         auto put_d = [&](uint32_t e, const fe9& v) { st_stream(va + (((size_t)e << Llo) + g) * batch + q0 + q, F::pack(F::freeze(v))); };
         put_d(u4, lo0); put_d(u4 + G / 2, hi0); put_d(u4 + G / 4, lo1); put_d(u4 + G / 4 + G / 2, hi1);
+        return;
+    }
+    if (EVAL == 2) {
+        fe s[4] = {F::pack(F::freeze(lo0)), F::pack(F::freeze(lo1)), F::pack(F::freeze(hi0)), F::pack(F::freeze(hi1))};      // elements u4 + {0, 1, 2, 3} * G/4
+        const size_t mq = (size_t)g * (G / 4) + u4, o = mq >> 1, half = mq & 1, noct = ((size_t)1 << L) / 8, p = q0 + q;
+        const uint32_t c = (uint32_t)qd.c, cmask = (1u << c) - 1, D = 1u << (c - 1);
+        uint32_t carry = 0;
+        for (int j = 0; j < qd.nwin; j++) {
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t raw = (s[i].l[0] & cmask) + ((carry >> i) & 1u);
+#pragma unroll
+                for (int k = 0; k < 7; k++) s[i].l[k] = __builtin_amdgcn_alignbit(s[i].l[k + 1], s[i].l[k], c);
+                s[i].l[7] >>= c;
+                int32_t dg = (int32_t)raw;
+                if (raw >= D) { dg -= (int32_t)(1u << c); carry |= 1u << i; } else carry &= ~(1u << i);
+                w[i] = (uint32_t)dg;
+            }
+            const size_t at = ((size_t)j * noct + o) * batch + p;
+            if (c > 16) qd.digits[2 * at + half] = make_uint4(w[0], w[1], w[2], w[3]);
+            else reinterpret_cast<uint2*>(qd.digits + at)[half] = make_uint2((w[0] & 0xFFFFu) | (w[1] << 16), (w[2] & 0xFFFFu) | (w[3] << 16));
+        }
         return;
     }
     auto first_dif = [&](uint32_t e1, const fe9& lo, const fe9& hi) {       // first DIF stage (s = 0) on d: same pairs; twiddle exponent = gidx(e1) mod n/2
@@ -343,12 +370,16 @@ __global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, co
 }  // namespace
 
 namespace {
-hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, bool eval);
+hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, int eval, const QuotDigits& qd);
 }
-hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols) { return launch_quotient(p, a, b, c, m, batch, s, ncols, false); }
-hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols) { return launch_quotient(p, a, b, nullptr, m, batch, s, ncols, true); }
+hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols) { return launch_quotient(p, a, b, c, m, batch, s, ncols, 0, QuotDigits{nullptr, 0, 0}); }
+hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols) { return launch_quotient(p, a, b, nullptr, m, batch, s, ncols, 1, QuotDigits{nullptr, 0, 0}); }
+hipError_t launch_compute_d_digits(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, const QuotDigits& qd, hipStream_t s) {
+    if (!qd.digits || qd.c < 4 || qd.c > MSM_MAX_WINDOW || qd.nwin != msm_windows(qd.c)) return hipErrorInvalidValue;
+    return launch_quotient(p, a, b, nullptr, m, batch, s, 0, 2, qd);
+}
 namespace {
-hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, bool eval) {
+hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, int eval, const QuotDigits& qd) {
     const int L = p.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     if (L < NTT_MIN_LOG2 || L > NTT_MAX_LOG2 || batch % P) return hipErrorInvalidValue;      // block sizes / launch bounds below assume this range
     const unsigned G = 1u << Lhi, Cn = 1u << Llo;
@@ -359,13 +390,14 @@ hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size
     auto opt_in = [&](const void* f, size_t lds) { if (e == hipSuccess && lds > 65536) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
     // 2^17 domains (AES-V2): 72 KiB tiles need the opt-in LDS limit (a CU has 160 KiB)
     opt_in(reinterpret_cast<const void*>(k_ntt_dif_strided), lds_s);
-    opt_in(eval ? reinterpret_cast<const void*>(k_ntt_pointwise_strided<true>) : reinterpret_cast<const void*>(k_ntt_pointwise_strided<false>), lds_s);
+    opt_in(eval == 2 ? reinterpret_cast<const void*>(k_ntt_pointwise_strided<2>) : eval ? reinterpret_cast<const void*>(k_ntt_pointwise_strided<1>) : reinterpret_cast<const void*>(k_ntt_pointwise_strided<0>), lds_s);
     opt_in(reinterpret_cast<const void*>(k_ntt_mid_contig), lds_c); opt_in(reinterpret_cast<const void*>(k_ntt_final_contig), lds_c);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, eval ? 2 : 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch);
     hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 2), dim3(Cn / 4 * P), lds_c, s, p, a, b, c, batch);
-    if (eval) { hipLaunchKernelGGL(k_ntt_pointwise_strided<true>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch); return hipGetLastError(); }
-    hipLaunchKernelGGL(k_ntt_pointwise_strided<false>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch);
+    if (eval == 2) { hipLaunchKernelGGL(k_ntt_pointwise_strided<2>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch, qd); return hipGetLastError(); }
+    if (eval) { hipLaunchKernelGGL(k_ntt_pointwise_strided<1>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch, qd); return hipGetLastError(); }
+    hipLaunchKernelGGL(k_ntt_pointwise_strided<0>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch, qd);
     hipLaunchKernelGGL(k_ntt_final_contig, dim3(G, pb, 1), dim3(Cn / 4 * P), lds_c, s, p, a, c, batch);
     return hipGetLastError();
 }

@@ -97,10 +97,11 @@ __global__ __launch_bounds__(64) void k_qb_stage(fe* Y, uint32_t half_n, int L, 
 }
 
 // XYZZ -> affine bases in the layout the table builders take (8 x 32-bit Montgomery images); status 2 = the point at infinity
-__global__ __launch_bounds__(64) void k_qb_finish(const fe* Y, uint32_t n, Aff<Fp>* out, uint8_t* status) {
+// perm (optional): out[i] = point perm[i] — the order the windowed MSM wants its bases in (kernels.hpp quot_digit_index)
+__global__ __launch_bounds__(64) void k_qb_finish(const fe* Y, uint32_t n, const uint32_t* perm, Aff<Fp>* out, uint8_t* status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Xyzz9<Fp29f> p = G1x::load_xyzz(Y + 4 * (size_t)i);
+    const Xyzz9<Fp29f> p = G1x::load_xyzz(Y + 4 * (size_t)(perm ? perm[i] : i));
     if (p.inf) { status[i] = 2; out[i] = Aff<Fp>{Fp::zero(), Fp::zero()}; return; }
     const Aff9<Fp29f> a = G1x::to_aff(p);
     out[i] = Aff<Fp>{qb_from_fp29(a.x), qb_from_fp29(a.y)};
@@ -110,13 +111,13 @@ __global__ __launch_bounds__(64) void k_qb_finish(const fe* Y, uint32_t n, Aff<F
 }  // namespace
 
 void launch_quot_bases(const G1Aff* zfile, const uint8_t* zstatus, int L, int mode, const fe* omega_inv, const fe* n_inv,
-                       fe* tw, G1Xyzz* scratch, G1Aff* out, uint8_t* status, hipStream_t s) {
+                       fe* tw, G1Xyzz* scratch, const uint32_t* perm, G1Aff* out, uint8_t* status, hipStream_t s) {
     const uint32_t n = 1u << L, hn = n / 2;
     fe* Y = reinterpret_cast<fe*>(scratch);
     hipLaunchKernelGGL(k_qb_twiddles, dim3((hn + 63) / 64), dim3(64), 0, s, omega_inv, hn, tw);
     hipLaunchKernelGGL(k_qb_load, dim3((n + 63) / 64), dim3(64), 0, s, reinterpret_cast<const Aff<Fp>*>(zfile), zstatus, n, L, mode, omega_inv, n_inv, Y);
     for (int st = 0; st < L; st++) hipLaunchKernelGGL(k_qb_stage, dim3((hn + 63) / 64), dim3(64), 0, s, Y, hn, L, st, tw);
-    hipLaunchKernelGGL(k_qb_finish, dim3((n + 63) / 64), dim3(64), 0, s, Y, n, reinterpret_cast<Aff<Fp>*>(out), status);
+    hipLaunchKernelGGL(k_qb_finish, dim3((n + 63) / 64), dim3(64), 0, s, Y, n, perm, reinterpret_cast<Aff<Fp>*>(out), status);
 }
 
 }  // namespace gsc

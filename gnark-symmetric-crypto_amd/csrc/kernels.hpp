@@ -98,12 +98,24 @@ hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, siz
 // The quotient in EVALUATION form: only the four transforms of a and b; on return a[i] = A(zeta w^i) B(zeta w^i) * 2^261 mod r as a
 // canonical integer, natural order (b overwritten, c not touched): the scalars of the bases V_i of launch_quot_bases.
 hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols = 0);
+// The same, but the last kernel recodes d itself: it writes the signed c-bit digits of the windowed MSM (launch_msm_win_g1's format, see
+// launch_msm_recode) instead of d — no scalar vector in memory, no recoding pass.  A thread of that kernel holds d at four indices, which
+// become four consecutive bases: table position t of the MSM set belongs to the index quot_digit_index(L, t) (the engine lays the bases
+// V out in that order).  Whole batches only (ncols = 0).
+struct QuotDigits { uint4* digits; int c, nwin; };
+hipError_t launch_compute_d_digits(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, const QuotDigits& qd, hipStream_t s);
+inline uint32_t quot_digit_index(int L, uint32_t t) {
+    const int Lhi = (L + 1) / 2, Llo = L - Lhi; const uint32_t quarter = (1u << Lhi) / 4;
+    const uint32_t kq = t & 3, m = t >> 2, u4 = m % quarter, g = m / quarter;
+    return ((u4 + kq * quarter) << Llo) + g;
+}
 // InitAlgorithm: the key's quotient bases in evaluation form (k_quot_bases.hip).  zfile: the n - 1 points of pk.G1.Z as stored
 // (bit-reversed order), zstatus[i] = 2 for a point at infinity; n = 2^L.  mode 0: out[i] = U_i = (1/2n) sum_k w^(-ik) Z_k (scalars: the
 // solver's c_i); mode 1: out[i] = V_i = -(1 / (2n 2^261)) sum_k zeta^(-k) w^(-ik) Z_k (scalars: launch_compute_d's output).  Natural order,
 // n points, affine (8 x 32-bit Montgomery images); status[i] = 2 for the point at infinity.  tw: n/2 elements, scratch: n points.
+// perm (device, n entries, or nullptr): out[i] = the point of index perm[i] instead of i.
 void launch_quot_bases(const G1Aff* zfile, const uint8_t* zstatus, int L, int mode, const fe* omega_inv, const fe* n_inv,
-                       fe* tw, G1Xyzz* scratch, G1Aff* out, uint8_t* status, hipStream_t s);
+                       fe* tw, G1Xyzz* scratch, const uint32_t* perm, G1Aff* out, uint8_t* status, hipStream_t s);
 
 // ---- multi-scalar multiplication (k_msm_win.hip, k_msm.hip) ----
 // Every MSM of the prover is a fixed-base sum over a set of the proving key (A, B1, B2, K, Z, commitment bases) for a batch of

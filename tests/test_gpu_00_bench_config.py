@@ -34,7 +34,7 @@ g = gsc_loader.load()
 assert g.init_algorithm(0, bench.golden("pk.chacha20"), bench.golden("r1cs.chacha20"))
 d = g.describe(0)
 print("DESCRIBE", d)
-assert "window_z=17 " in d and "max_batch=8192 " in d and "lanes=1 " in d and "quotient=evaluation-form" in d, d
+assert "window_z=17 " in d and "max_batch=8192 " in d and "lanes=1 " in d and "quotient=evaluation-form+digits" in d, d
 n = 8192
 recs = bench.xoshiro_records(n, 0x7E57 << 20)
 g.set_deterministic_randomness(int(sys.argv[3]), int(sys.argv[4]), 0)
@@ -93,7 +93,7 @@ algo, name = int(sys.argv[5]), sys.argv[6]
 assert g.init_algorithm(algo, open(sys.argv[7], "rb").read(), bench.golden("r1cs." + name))
 d = g.describe(algo)
 print("DESCRIBE", d)
-assert "window_z=15 " in d and "window_w=15 " in d and "max_batch=1024 " in d and "lanes=2 " in d and "quotient=evaluation-form" in d, d
+assert "window_z=15 " in d and "window_w=15 " in d and "max_batch=1024 " in d and "lanes=2 " in d and "quotient=evaluation-form+digits" in d, d
 n = 1024
 recs = bench.provable(bench.xoshiro_records(n, 0xAE5 << 20), name)
 g.set_deterministic_randomness(int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[3]) ^ 0x5555)
