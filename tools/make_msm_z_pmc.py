@@ -1,13 +1,20 @@
 """Builds profiles/rNN_msm_z_pmc.json (what bench.py replays as roofline.traffic) from three rocprofv3 --pmc passes of
 `bench.py --steps 1 --warmup 1 --no-cpu-baseline`: FETCH_SIZE, WRITE_SIZE, TCC_HIT/MISS/REQ/EA0_RDREQ.
-usage: make_msm_z_pmc.py <fetch.csv> <write.csv> <tcc.csv> <out.json> [window_z] [batch]"""
+usage: make_msm_z_pmc.py <fetch.csv> <write.csv> <tcc.csv> <out.json> [window_z] [batch] [nbases]
+(nbases: 32767 for the coefficient-form quotient, 32768 for the evaluation form, whose batches also launch the same kernel template with narrow
+digits for the wide rows of c: only the Z launch — the wide-digit instantiation at c = 17 — is counted)"""
 import csv, json, math, sys
+
+
+C_ARG = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 
 
 def per_launch(path, want):
     acc = {}; ids = set(); ms = 0.0
     for r in csv.DictReader(open(path)):
         if "k_msm_win" not in r["Kernel_Name"] or "Fp29f" not in r["Kernel_Name"]:
+            continue
+        if C_ARG > 16 and "true>" not in r["Kernel_Name"]:
             continue
         if r["Dispatch_Id"] not in ids:
             ids.add(r["Dispatch_Id"]); ms += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
@@ -21,7 +28,7 @@ write, ms_w, n_w = per_launch(sys.argv[2], ["WRITE_SIZE"])
 tcc, ms_t, n_t = per_launch(sys.argv[3], ["TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum"])
 c = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 batch = int(sys.argv[6]) if len(sys.argv) > 6 else 8192
-nbases, nwin = 32767, {17: 15, 16: 16, 15: 17, 14: 19, 13: 20}.get(c, math.ceil(254 / c))
+nbases, nwin = int(sys.argv[7]) if len(sys.argv) > 7 else 32767, {17: 15, 16: 16, 15: 17, 14: 19, 13: 20}.get(c, math.ceil(254 / c))
 E = 1 << (c - 1); g = 384 * 64.0                       # entries per row; lanes of one XCD's 384 resident waves gathering from the same row
 model = 1.0 - (E / g) * (1.0 - math.exp(-g / E))
 out = {
