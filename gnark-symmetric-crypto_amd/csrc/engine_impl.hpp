@@ -97,7 +97,7 @@ class AlgorithmImpl {
     // latency layout mZfew keep the coefficient form (it holds the key's own Z).
     bool quotient_eval = false; MsmSet<G1Aff> mC; std::vector<uint8_t> row_class_c;
     // ... and the last quotient kernel writes the digits of d itself (launch_compute_d_digits): mZ's table positions follow quot_digit_index,
-    // whole batches skip the recoding pass and run the Z sum first (its digits sit in the lane's digit buffer until then)
+    // whole batches skip the recoding pass; the other sets recode into a (small) digit buffer of their own meanwhile (Lane::d_digits_w)
     bool fuse_z_digits = false;
     // batch buffers: one set per lane.  A lane = a HIP stream with its own witness / polynomial / partial-sum buffers; with more than
     // one full lane big batches are cut into chunks that the lanes prove concurrently.  Measured on MI355X: for FULL
@@ -119,6 +119,7 @@ class AlgorithmImpl {
         DevBuf<uint4> d_digits_s2; DevBuf<uint8_t> d_gok_s2;                                        // side2's digits (its partial sums are the G2 buffers, which nothing else uses)
         DevBuf<uint4> d_digits_s; DevBuf<uint8_t> d_gok_s; DevBuf<G1Xyzz> d_part1c, d_part1d;      // the side stream's MSM scratch (A and B1 of a latency-path call)
         DevBuf<uint4> d_digits;                                                   // signed digits [window][octet][proof]
+        DevBuf<uint4> d_digits_w;      // fuse_z_digits: the digits of every set but Z (Z's are written by the last quotient kernel into d_digits and must survive until its sum runs)
         // per-window sums [window][proof] and flat-part sums [proof], one pair per set: the Horner passes of several sets are deferred
         // and run as one launch (MsmHornerJobs), so their inputs must not share storage
         static constexpr int NSETS = 8;      // A, B1, K, Z, Ped, PedSigma, Z (latency layout), C (evaluation-form quotient)

@@ -119,12 +119,12 @@ void AlgorithmImpl::run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* sca
                 launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
         return;
     }
-    run_msm(ln, MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, digits_ready, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
+    run_msm(ln, MsmCtx{ln.stream, ln.d_digits_w.p && &set != &mZ ? ln.d_digits_w.p : ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, digits_ready, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
 }
 
 void AlgorithmImpl::run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum, bool side) {
     if (side && (!set.latency_flat() || B != 64)) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
-    run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_reduce_few_g2);
+    run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits_w.p ? ln.d_digits_w.p : ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_reduce_few_g2);
 }
 
 void AlgorithmImpl::fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
@@ -280,10 +280,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     } else HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0));      // latency path: the statements' columns only
     HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
     if (dbg && !eval) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
-    // 3. MSMs.  With the digits of d already in the lane's digit buffer (fuse_z_digits) the Z sum goes first: every other set recodes into that buffer.
-    const bool z_first = eval && fuse_z_digits && !few_call;
-    if (z_first) run_msm_g1(ln, mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call, false, true);
-    // A and B1 next: the two scalar multiplications of the assembly only need those two sums and run on a side stream
+    // 3. MSMs.  (With fuse_z_digits the digits of d are already in the lane's Z digit buffer; every other set recodes into d_digits_w.)
+    const bool z_digits_ready = eval && fuse_z_digits && !few_call;
+    // A and B1 first: the two scalar multiplications of the assembly only need those two sums and run on a side stream
     // beside the remaining MSMs.
     if (!early_ab) {
         run_msm_g1(ln, mA, ln.d_W.p, 1, B, ln.d_sumA.p);
@@ -306,7 +305,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         HIP_CHECK(hipMemsetAsync(ln.d_C.p + domain_n * B, 0, B * sizeof(fe), ln.stream));
         run_msm_g1(ln, mC, ln.d_C.p, 1, B, ln.d_sumC.p);
     }
-    if (!z_first) run_msm_g1(ln, use_zfew ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call);
+    run_msm_g1(ln, use_zfew ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call, false, z_digits_ready);
     if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
     flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
     if (has_commitment) launch_points_to_affine_be(ln.d_sumPok.p, B, ln.d_cpts.p + 64 * B, ln.d_flags.p, 16, ln.stream);

@@ -440,7 +440,7 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     HIP_CHECK(hipMemsetAsync(ln.d_W.p, 0, ln.d_W.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_A.p, 0, ln.d_A.n * sizeof(fe), ln.stream));
     HIP_CHECK(hipMemsetAsync(ln.d_B.p, 0, ln.d_B.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_C.p, 0, ln.d_C.n * sizeof(fe), ln.stream));
     // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
-    size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, dgz = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto need = [&](auto& m, size_t b, size_t& pa, size_t& pb, size_t& sj) {
         auto part = [&](size_t nb, size_t ns, size_t cols) {
             if (ns * cols > pa) pa = ns * cols;
@@ -457,9 +457,13 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     };
     MsmSet<G1Aff>* g1sets[Lane::NSETS] = {&mA, &mB1, &mK, &mZ, &mPed, &mPedSigma, &mZfew, &mC};
     for (size_t b = 64; b <= B; b += 64) {
-        for (int k = 0; k < Lane::NSETS; k++) if (g1sets[k] != &mZfew || b == 64) need(*g1sets[k], b, p1, p1b, sj1[k]);      // the latency layout only serves 64-column batches
+        for (int k = 0; k < Lane::NSETS; k++) if (g1sets[k] != &mZfew || b == 64) {      // the latency layout only serves 64-column batches
+            if (fuse_z_digits && g1sets[k] == &mZ) { const size_t keep = dg; dg = 0; need(mZ, b, p1, p1b, sj1[k]); if (dg > dgz) dgz = dg; dg = keep; }      // Z's digits: a buffer of their own
+            else need(*g1sets[k], b, p1, p1b, sj1[k]);
+        }
         need(mB2, b, p2, p2b, sj2);
     }
+    if (fuse_z_digits) { ln.d_digits_w.alloc(dg ? dg : 1); dg = dgz; }
     ln.d_part1a.alloc(p1); ln.d_part1b.alloc(p1b); ln.d_part2a.alloc(p2); ln.d_part2b.alloc(p2b);
     ln.d_digits.alloc(dg); ln.d_gok.alloc(gk ? gk : 1);
     {
