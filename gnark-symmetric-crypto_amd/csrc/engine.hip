@@ -45,6 +45,8 @@ EngineConfig config_from_env() {
     c.few_wide = env_int("GSC_FEW_WIDE", 1);
     c.quotient_eval = env_int("GSC_QUOTIENT_EVAL", 1);
     c.fuse_z_digits = env_int("GSC_FUSE_Z_DIGITS", 1);
+    c.small_witness = env_int("GSC_SMALL_WITNESS", 1);
+    if (c.small_witness < 0 || c.small_witness > 2 || (c.small_witness == 2 && !test_hooks_enabled())) throw std::runtime_error("GSC_SMALL_WITNESS must be 0 or 1");
     if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");
     c.trace_host = getenv("GSC_TRACE_HOST") != nullptr;
     if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; }
@@ -105,6 +107,7 @@ std::string Algorithm::describe() const {
     std::string out = buf;
     if (impl_->quotient_eval) out += std::string(" quotient=evaluation-form") + (impl_->fuse_z_digits ? "+digits" : "") + "(c: " + std::to_string(impl_->mC.nbit) + " grouped + " + std::to_string(impl_->mC.nflat - impl_->mC.nbit) + " flat + " + std::to_string(impl_->mC.nwide) + " windowed)";
     else out += " quotient=coefficient-form";
+    out += impl_->small.ok ? " witness=small-integer(" + std::to_string(impl_->small.n_levels) + " chained levels, fallbacks " + std::to_string(impl_->small_fallbacks.load()) + ")" : " witness=generic";
     out += " served(calls/statements)=";
     const auto sv = picker_->served();
     for (size_t i = 0; i < sv.size(); i++) out += (i ? "," : "") + std::to_string(sv[i].calls) + "/" + std::to_string(sv[i].statements);

@@ -49,6 +49,9 @@ struct EngineConfig {
     int quotient_eval = 1;       // GSC_QUOTIENT_EVAL: batch calls take the quotient in evaluation form (k_quot_bases.hip: four transforms instead of six, the Z sum over the
                                  // bases V_i plus a flat sum over the solver's c); 0 = coefficient form for every call (six transforms, the key's own Z bases)
     int fuse_z_digits = 1;       // GSC_FUSE_Z_DIGITS: in evaluation form the last quotient kernel writes the signed digits of d itself (no scalar vector, no recoding pass); 0 = it writes d
+    int small_witness = 1;       // GSC_SMALL_WITNESS: circuits whose whole witness is small integers (ChaCha20-V3) are solved by the integer kernels on byte planes
+                                 // (wit_small.hpp) in every call beyond the latency path; 0 = always the generic field-arithmetic solver;
+                                 // 2 (test hooks only) = every constraint row predicted narrow: the kernels notice, the chunk is solved again generically
     bool trace_host = false;     // GSC_TRACE_HOST: host-side timing lines on stderr (InitAlgorithm breakdown, per-chunk enqueue / wait / serialise)
     // diagnostics that change what the device does: honoured only when the test hooks were enabled at load time (test_hooks_enabled())
     bool solver_trace = false;   // GSC_SOLVER_TRACE: per-level clock stamps of the witness kernels

@@ -6,6 +6,7 @@
 #include "engine.hpp"
 #include "formats.hpp"
 #include "kernels.hpp"
+#include "wit_small.hpp"
 #include <atomic>
 #include <condition_variable>
 #include <memory>
@@ -53,7 +54,7 @@ FewSolverChain& few_solver_chain(int device);      // one per device, never dest
 class AlgorithmImpl {
   public:
     Cipher cipher; EngineConfig cfg;
-    size_t n_wires = 0, n_public = 0, n_constraints = 0, domain_n = 0; int L = 0;
+    size_t n_wires = 0, n_public = 0, n_inputs = 0, n_constraints = 0, domain_n = 0; int L = 0;      // n_inputs: public + secret wires (what k_assign_* writes)
     bool has_commitment = false;
     // lanes are handed out one chunk at a time; concurrent calls (and the chunks of one call) take whichever lane is free
     std::mutex pool_mu; std::condition_variable pool_cv; std::vector<uint8_t> lane_busy;
@@ -88,6 +89,13 @@ class AlgorithmImpl {
     DevBuf<uint32_t> few_count_ops, few_count_qoff; std::vector<uint32_t> few_count_first;
     DevBuf<uint32_t> few_ops, few_terms, few_lstart;          // the same program laid out for k_solver_few (formats.hpp FewProgram)
     uint32_t n_levels = 0, commit_level = 0; std::vector<uint32_t> level_width; std::vector<uint8_t> level_kind; std::vector<uint32_t> level_long; int has_div = 0;
+    // The small-integer witness path (wit_small.hpp): built after calibrate() for circuits that qualify (ChaCha20-V3); small.ok says so.
+    // small keeps the sizes and the per-row classes; the item lists live on the device.
+    SmallProgram small; std::vector<uint8_t> row_class_a, row_class_b;
+    DevBuf<uint32_t> ws_tiny, ws_parts, ws_bits, ws_twire, ws_levels, ws_rtiny, ws_rgen, ws_rtwire; DevBuf<long long> ws_tcoef, ws_rtcoef;
+    DevBuf<uint8_t> ws_cls_a, ws_cls_b, ws_cls_c;      // per constraint row: 0 = byte plane, 1 = 32-byte element
+    void init_small(const SolverProgram& sp);
+    std::atomic<uint64_t> small_fallbacks{0};      // chunks that had to be solved again generically (gsc_describe)
     // NTT
     DevBuf<int32_t> tw_fwd, tw_inv, qr; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n
     // MSM sets
@@ -115,6 +123,7 @@ class AlgorithmImpl {
         DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync; DevBuf<GlvSplit> d_glv;
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
+        DevBuf<int8_t> d_W8, d_A8, d_B8, d_C8; DevBuf<uint32_t> d_wsflag;      // byte planes of the small-integer witness path; its "a prediction failed" flag
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_sumC, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
         DevBuf<uint4> d_digits_s2; DevBuf<uint8_t> d_gok_s2;                                        // side2's digits (its partial sums are the G2 buffers, which nothing else uses)
         DevBuf<uint4> d_digits_s; DevBuf<uint8_t> d_gok_s; DevBuf<G1Xyzz> d_part1c, d_part1d;      // the side stream's MSM scratch (A and B1 of a latency-path call)
@@ -137,7 +146,7 @@ class AlgorithmImpl {
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf);
     ~AlgorithmImpl() { lanes.clear(); if (stream) (void)hipStreamDestroy(stream); }
 
-    void init_program(const R1csFile& cs);
+    std::unique_ptr<SolverProgram> init_program(const R1csFile& cs);
 
     static void pack_inputs(const ProofRequest* reqs, size_t n, size_t B, std::vector<uint8_t>& h_in, std::vector<uint8_t>& h_rs);
 
@@ -214,7 +223,7 @@ class AlgorithmImpl {
 
     void fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out);
 
-    void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver = true);
+    void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver = true, bool allow_small = true);
 
     // gnark proof.WriteTo: Ar | Bs | Krs compressed, u32be nbCommitments, commitments, CommitmentPok
     void serialize(const uint8_t* o, uint8_t flags, uint32_t status, const uint8_t* commitment_xy, const uint8_t* pok_xy, ProofResult& res) const;

@@ -133,7 +133,7 @@ void AlgorithmImpl::fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B,
     HIP_CHECK(hipStreamSynchronize(ln.stream));
 }
 
-void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver) {
+void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver, bool allow_small) {
     const size_t B = (n + 63) / 64 * 64;
     ln.n_real = n;
     const bool trace = cfg.trace_host;
@@ -178,6 +178,8 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         if (k) few_solver = false;
     }
     const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
+    // Circuits whose witness is small integers (ChaCha20-V3): the integer kernels on byte planes (wit_small.hpp) instead of the level launches
+    const bool small_call = small.ok && allow_small && !latency_call && !strace;
     if (few_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
     SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
                      ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, 1u << 21, 0u, n_levels, nullptr};
@@ -221,6 +223,18 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         launch_challenge_from_point(ln.d_cpts.p, ln.d_commit.p, B, ln.stream);
         h_cpts.resize(128 * B);
         run_levels(commit_level, n_levels);
+    } else if (small_call) {
+        HIP_CHECK(hipMemsetAsync(ln.d_wsflag.p, 0, 4, ln.stream));
+        launch_wit_narrow(ln.d_W.p, B, n_inputs, ln.d_W8.p, small.rows_per_group, ln.d_wsflag.p, ln.stream);
+        launch_wit_chain(WitChainArgs{ws_tiny.p, ws_parts.p, ws_bits.p, ws_twire.p, ws_tcoef.p, ws_levels.p, small.n_levels, ln.d_W8.p, small.rows_per_group, ln.d_wsflag.p}, B / 64, 512 * (size_t)small.max_slots, ln.stream);
+        const uint32_t per_chunk = 4 * WS_IB;
+        launch_wit_rows(WitRowsArgs{ws_rtiny.p, small.n_rtiny, per_chunk, (small.n_rtiny + per_chunk - 1) / per_chunk, ws_rgen.p, small.n_rgen, ws_rtwire.p, ws_rtcoef.p, ln.d_W8.p, small.rows_per_group,
+                                    ln.d_A8.p, ln.d_B8.p, ln.d_C8.p, n_constraints, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p, ln.d_wsflag.p}, B / 64, ln.stream);
+        // the byte planes as 32-byte elements for the consumers that have no byte-plane form (yet)
+        launch_wit_expand(ln.d_W8.p, small.rows_per_group, n_wires, nullptr, ln.d_W.p, B, ln.stream);
+        launch_wit_expand(ln.d_A8.p, n_constraints, n_constraints, ws_cls_a.p, ln.d_A.p, B, ln.stream);
+        launch_wit_expand(ln.d_B8.p, n_constraints, n_constraints, ws_cls_b.p, ln.d_B.p, B, ln.stream);
+        launch_wit_expand(ln.d_C8.p, n_constraints, n_constraints, ws_cls_c.p, ln.d_C.p, B, ln.stream);
     } else run_levels(0, n_levels);
     if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
     if (strace) {
@@ -322,8 +336,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     HIP_CHECK(hipMemcpyAsync(h_flags.data(), ln.d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, ln.stream));
     HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
     if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
-    uint32_t h_fsync[2] = {0, 0};
+    uint32_t h_fsync[2] = {0, 0}, h_wsflag = 0;
     if (few_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
+    if (small_call) HIP_CHECK(hipMemcpyAsync(&h_wsflag, ln.d_wsflag.p, 4, hipMemcpyDeviceToHost, ln.stream));
     const auto tc1 = std::chrono::steady_clock::now();
     HIP_CHECK(hipStreamSynchronize(ln.stream));
     const auto tc2 = std::chrono::steady_clock::now();
@@ -332,7 +347,11 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         if (!warned.exchange(true)) fprintf(stderr, "libprove: the resident witness kernel could not hold the device (shared with another process?); solving level by level\n");
         const uint32_t pen = few_penalty.load();
         few_skip.store(pen); few_penalty.store(pen < 4096 ? pen * 2 : 4096);
-        return prove_chunk(ln, reqs, n, results, dbg, false);
+        return prove_chunk(ln, reqs, n, results, dbg, false, allow_small);
+    }
+    if (h_wsflag) {      // a value did not fit the byte plane it was predicted for: the whole chunk again with the generic solver (results never depend on predictions)
+        small_fallbacks++;
+        return prove_chunk(ln, reqs, n, results, dbg, allow_few_solver, false);
     }
     if (few_solver) few_penalty.store(16);
     for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }

@@ -35,8 +35,11 @@ AlgorithmImpl::AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const u
     R1csFile cs = parse_r1cs(r1cs, r1cs_len);
     PkFile key = parse_pk(pk, pk_len);
     const auto t1 = now();
-    init_program(cs);
-    calibrate();
+    {
+        const std::unique_ptr<SolverProgram> sp = init_program(cs);
+        calibrate();
+        init_small(*sp);
+    }
     const auto t2 = now();
     init_key(cs, key);
     const auto t3 = now();
@@ -62,12 +65,13 @@ AlgorithmImpl::AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const u
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
-void AlgorithmImpl::init_program(const R1csFile& cs) {
-    n_wires = cs.n_wires(); n_public = cs.n_public; n_constraints = cs.n_constraints; has_commitment = cs.has_commitment;
+std::unique_ptr<SolverProgram> AlgorithmImpl::init_program(const R1csFile& cs) {
+    n_wires = cs.n_wires(); n_public = cs.n_public; n_inputs = cs.n_public + cs.n_secret; n_constraints = cs.n_constraints; has_commitment = cs.has_commitment;
     const size_t expect_in = cipher == CHACHA20 ? 1408 : cipher == AES_128 ? 157 : 173;
     if (cs.n_public - 1 + cs.n_secret != expect_in) throw std::runtime_error("r1cs: witness size does not match the cipher's circuit");
     if (cs.n_coeff() < 5 || memcmp(cs.coeff_limbs.data(), kSmallCoeffs, sizeof kSmallCoeffs)) throw std::runtime_error("r1cs: coefficient ids 0..4 are not 0,1,2,-1,-2");
-    SolverProgram sp = build_solver_program(cs);
+    std::unique_ptr<SolverProgram> keep(new SolverProgram(build_solver_program(cs)));
+    const SolverProgram& sp = *keep;
     n_levels = (uint32_t)sp.n_levels; commit_level = (uint32_t)sp.commit_level; has_div = sp.n_inversions ? 1 : 0;
     level_width.resize(n_levels); for (uint32_t l = 0; l < n_levels; l++) level_width[l] = sp.sched[2 + l] - sp.sched[1 + l];
     level_kind = sp.level_kind; level_long = sp.level_long;
@@ -97,6 +101,34 @@ void AlgorithmImpl::init_program(const R1csFile& cs) {
         if (flag) throw std::runtime_error("r1cs: unsupported lookup table (index column is not 0..n-1)");
     }
     HIP_CHECK(hipStreamSynchronize(stream));
+    return keep;
+}
+
+// The small-integer witness program (wit_small.hpp), when the circuit qualifies: coefficients as integers (from the device: no field
+// arithmetic on the host), the calibration classes of wires and constraint rows, the item lists uploaded once.
+void AlgorithmImpl::init_small(const SolverProgram& sp) {
+    if (!cfg.small_witness) return;
+    const size_t nc = coeff.n;
+    DevBuf<long long> d_c(nc ? nc : 1); DevBuf<uint8_t> d_ok(nc ? nc : 1);
+    std::vector<long long> hc(nc); std::vector<uint8_t> ok(nc);
+    launch_coeff_small(coeff.p, nc, d_c.p, d_ok.p, stream);
+    HIP_CHECK(hipGetLastError());
+    if (nc) { HIP_CHECK(hipMemcpyAsync(hc.data(), d_c.p, nc * 8, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipMemcpyAsync(ok.data(), d_ok.p, nc, hipMemcpyDeviceToHost, stream)); }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<int64_t> ci(hc.begin(), hc.end());
+    std::vector<uint8_t> ca = row_class_a, cb = row_class_b, cc = row_class_c;
+    if (cfg.small_witness == 2) { std::fill(ca.begin(), ca.end(), 0); std::fill(cb.begin(), cb.end(), 0); std::fill(cc.begin(), cc.end(), 0); }      // test: wrong on purpose
+    small = build_small_program(sp, n_wires, n_constraints, ci, ok, row_class, ca, cb, cc);
+    if (cfg.trace_host) fprintf(stderr, "InitAlgorithm(%d): small-integer witness path: %s%s\n", (int)cipher, small.ok ? "yes" : "no — ", small.ok ? "" : small.why.c_str());
+    if (!small.ok) return;
+    auto up32 = [&](DevBuf<uint32_t>& d, std::vector<uint32_t>& v, size_t pad) { v.resize(v.size() + pad, 0u); d.alloc(v.size()); d.upload(v.data(), v.size(), stream); };
+    auto up64 = [&](DevBuf<long long>& d, std::vector<int64_t>& v, size_t pad) { v.resize(v.size() + pad, 0); d.alloc(v.size()); d.upload(reinterpret_cast<const long long*>(v.data()), v.size(), stream); };
+    // (the kernels fetch descriptors and terms a whole wave at a time: 128 / 64 words beyond the last item may be read)
+    up32(ws_tiny, small.tiny, 128); up32(ws_parts, small.parts, 4); up32(ws_bits, small.bits, 4); up32(ws_twire, small.twire, 64); up64(ws_tcoef, small.tcoef, 64); up32(ws_levels, small.levels, 6);
+    up32(ws_rtiny, small.rtiny, 128); up32(ws_rgen, small.rgen, 8); up32(ws_rtwire, small.rtwire, 64); up64(ws_rtcoef, small.rtcoef, 64);
+    ws_cls_a.alloc(n_constraints); ws_cls_b.alloc(n_constraints); ws_cls_c.alloc(n_constraints);
+    ws_cls_a.upload(small.cls_a.data(), n_constraints, stream); ws_cls_b.upload(small.cls_b.data(), n_constraints, stream); ws_cls_c.upload(small.cls_c.data(), n_constraints, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
 }
 
 void AlgorithmImpl::pack_inputs(const ProofRequest* reqs, size_t n, size_t B, std::vector<uint8_t>& h_in, std::vector<uint8_t>& h_rs) {
@@ -116,8 +148,9 @@ void AlgorithmImpl::calibrate() {
     row_class.assign(n_wires + 4, 255);
     row_class[n_wires] = row_class[n_wires + 1] = row_class[n_wires + 2] = 254;     // r, s, -rs: uniform scalars
     row_class_c.assign(n_constraints, 255);                                         // the rows of c (evaluation-form quotient): same prediction, same fallbacks
+    row_class_a.assign(n_constraints, 255); row_class_b.assign(n_constraints, 255);  // the rows of a and b (byte planes of the small-integer witness path)
     if (cfg.bit_groups <= 0) return;
-    if (cfg.bit_groups >= 2) { std::fill(row_class.begin(), row_class.begin() + n_wires, 0); std::fill(row_class_c.begin(), row_class_c.end(), 0); return; }
+    if (cfg.bit_groups >= 2) { std::fill(row_class.begin(), row_class.begin() + n_wires, 0); std::fill(row_class_c.begin(), row_class_c.end(), 0); std::fill(row_class_a.begin(), row_class_a.end(), 0); std::fill(row_class_b.begin(), row_class_b.end(), 0); return; }
     const size_t B = 64;
     std::vector<ProofRequest> reqs(B);
     uint64_t x = 0x9E3779B97F4A7C15ull;
@@ -157,6 +190,12 @@ void AlgorithmImpl::calibrate() {
     launch_classify_wires(d_C.p, n_constraints, B, d_status.p, d_cls_c.p, stream);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(row_class_c.data(), d_cls_c.p, n_constraints, hipMemcpyDeviceToHost, stream));
+    DevBuf<uint8_t> d_cls_a(n_constraints), d_cls_b(n_constraints);
+    launch_classify_wires(d_A.p, n_constraints, B, d_status.p, d_cls_a.p, stream);
+    launch_classify_wires(d_B.p, n_constraints, B, d_status.p, d_cls_b.p, stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(row_class_a.data(), d_cls_a.p, n_constraints, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(row_class_b.data(), d_cls_b.p, n_constraints, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
@@ -439,6 +478,11 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     // (zero, later whatever an earlier call left there) because the transforms and MSMs run over whole 64-column batches
     HIP_CHECK(hipMemsetAsync(ln.d_W.p, 0, ln.d_W.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_A.p, 0, ln.d_A.n * sizeof(fe), ln.stream));
     HIP_CHECK(hipMemsetAsync(ln.d_B.p, 0, ln.d_B.n * sizeof(fe), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_C.p, 0, ln.d_C.n * sizeof(fe), ln.stream));
+    if (small.ok) {      // byte planes of the small-integer witness path (values 0, 1, 0xFF)
+        ln.d_W8.alloc((size_t)small.rows_per_group * B); ln.d_A8.alloc(n_constraints * B); ln.d_B8.alloc(n_constraints * B); ln.d_C8.alloc(n_constraints * B); ln.d_wsflag.alloc(1);
+        HIP_CHECK(hipMemsetAsync(ln.d_W8.p, 0, ln.d_W8.n, ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_A8.p, 0, ln.d_A8.n, ln.stream));
+        HIP_CHECK(hipMemsetAsync(ln.d_B8.p, 0, ln.d_B8.n, ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_C8.p, 0, ln.d_C8.n, ln.stream));
+    }
     // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
     size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, dgz = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto need = [&](auto& m, size_t b, size_t& pa, size_t& pb, size_t& sj) {

@@ -80,6 +80,30 @@ void launch_solver_count_few(const SolverArgs& a, const uint32_t* count_ops, con
 // *flag |= 1 if some OP_COUNT table's index column is not 0,1,2,... (InitAlgorithm-time validation)
 void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint32_t* count_ops, uint32_t nops, uint32_t* flag, hipStream_t s);
 
+// ---- small-integer witness path (k_wit_small.hip; program layout: wit_small.hpp) ----
+// Byte planes: W8[(group * rows_per_group + wire) * 64 + lane], A8 / B8 / C8[(group * crows + constraint) * 64 + lane], proof = 64 * group + lane;
+// values 0, 1, 0xFF (-1).  *flag |= 1 when a value predicted to fit a byte plane does not (the engine then solves the chunk again generically).
+struct WitChainArgs {
+    const uint32_t* tiny; const uint32_t* parts; const uint32_t* bits; const uint32_t* twire; const long long* tcoef; const uint32_t* levels; uint32_t nlevels;
+    int8_t* W8; size_t rows_per_group; uint32_t* flag;
+};
+// one workgroup of 16 waves per proof group; lds_bytes = 512 * SmallProgram::max_slots
+void launch_wit_chain(const WitChainArgs& a, size_t groups, size_t lds_bytes, hipStream_t s);
+struct WitRowsArgs {
+    const uint32_t* rtiny; uint32_t n_rtiny, tiny_per_chunk, n_tiny_chunks; const uint32_t* rgen; uint32_t n_rgen; const uint32_t* rtwire; const long long* rtcoef;
+    const int8_t* W8; size_t rows_per_group;
+    int8_t* A8; int8_t* B8; int8_t* C8; size_t crows;      // byte planes of the rows predicted narrow
+    fe* A; fe* B; fe* C; size_t batch;                     // [constraint][batch] Montgomery elements: the rows predicted wide
+    uint32_t* status; uint32_t* flag;
+};
+void launch_wit_rows(const WitRowsArgs& a, size_t groups, hipStream_t s);
+// mat[row * batch + p] = the plane's value as a Montgomery element, for rows 0 .. nrows-1 (cls != nullptr: only rows with cls[row] == 0)
+void launch_wit_expand(const int8_t* plane, size_t rows_per_group, size_t nrows, const uint8_t* cls, fe* mat, size_t batch, hipStream_t s);
+// rows 0 .. nrows-1 of W (32-byte elements: the input wires as k_assign_* wrote them) into the byte plane; a value outside {-1, 0, 1} raises *flag
+void launch_wit_narrow(const fe* W, size_t batch, size_t nrows, int8_t* W8, size_t rows_per_group, uint32_t* flag, hipStream_t s);
+// out[i] = coefficient i as an integer when |c| < 2^62 (ok[i] = 1), from its Montgomery image
+void launch_coeff_small(const fe* coeff, size_t n, long long* out, uint8_t* ok, hipStream_t s);
+
 // Calibration: cls[w] = 0 if wire w is 0 or 1 in every accepted proof of the batch (status == 0xFFFFFFFF), otherwise the largest bit
 // length of its sign-normalised value (1 = the wire also takes -1, .. 254).  W: [n_wires][batch] Montgomery.
 void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint32_t* status, uint8_t* cls, hipStream_t s);
