@@ -181,8 +181,8 @@ def debug_prove(params: dict):
 
 
 def describe(algorithm_id: int) -> str:
-    buf = C.create_string_buffer(1024)
-    lib().gsc_describe(algorithm_id, buf, 1024)
+    buf = C.create_string_buffer(4096)
+    lib().gsc_describe(algorithm_id, buf, 4096)
     return buf.value.decode()
 
 

@@ -204,6 +204,14 @@ g.set_deterministic_randomness(rnd.getrandbits(250), rnd.getrandbits(250), rnd.g
 ok, proofs, lens, cts = g.prove_raw(algo, recs, n)
 assert ok == n, ok
 print("DIGEST", hashlib.sha256(proofs + cts).hexdigest())
+print("DESCRIBE", g.describe(algo))
+if os.environ.get("TEST_KAT_STAGES"):      # the stage vectors of the App. E statement through whatever witness path this configuration takes
+    sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+    from conftest import KAT
+    g.set_deterministic_randomness(0, 0, 0)
+    d = g.debug_prove({"cipher": "chacha20", "key": list(KAT["key"]), "nonce": list(KAT["nonce"]), "counter": KAT["counter"], "input": list(KAT["input"])})
+    be = lambda vals: b"".join(v.to_bytes(32, "big") for v in vals)
+    print("KAT_W", hashlib.sha256(be(d["W"])).hexdigest()); print("KAT_ABC", hashlib.sha256(be(d["A"]) + be(d["B"]) + be(d["C"])).hexdigest())
 """
 
 
@@ -217,6 +225,32 @@ def _digest(env_extra, algo=0, pk_path=None):
     out = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     return [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
+
+
+def _child(env_extra, algo=0):
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_MIN_SPLIT="64", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_FEW_Z_GB="0", GSC_FEW_WIDE="0")
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", _OPTIONS_SCRIPT, ROOT, str(algo)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return {l.split(" ", 1)[0]: l.split(" ", 1)[1] for l in out.stdout.splitlines() if " " in l}
+
+
+def test_small_integer_witness_path_is_taken_checked_and_abandoned_when_a_prediction_fails():
+    # ChaCha20-V3's witness is small integers: batch calls solve it with the integer kernels on byte planes (csrc/wit_small.hpp) instead of
+    # 163 level launches of field arithmetic.  Same bytes as the generic solver (GSC_SMALL_WITNESS=0); the App. E stage hashes sha256(W),
+    # sha256(a|b|c) through it (GSC_FEW_PATH=0 sends even a single statement through the batch kernels); and with every constraint row
+    # predicted narrow (=2, a test hook) the kernels notice the 672 rows that are not, the chunk is solved again generically — same bytes.
+    small = _child({"TEST_KAT_STAGES": "1", "GSC_FEW_PATH": "0"})
+    assert "witness=small-integer(162 chained levels, fallbacks 0)" in small["DESCRIBE"], small["DESCRIBE"]
+    assert small["KAT_W"] == KAT["sha256_W"] and small["KAT_ABC"] == KAT["sha256_abc"]
+    generic = _child({"GSC_SMALL_WITNESS": "0", "GSC_FEW_PATH": "0"})
+    assert "witness=generic" in generic["DESCRIBE"] and generic["DIGEST"] == small["DIGEST"]
+    wrong = _child({"GSC_SMALL_WITNESS": "2", "GSC_FEW_PATH": "0"})
+    assert "witness=small-integer" in wrong["DESCRIBE"] and "fallbacks 0)" not in wrong["DESCRIBE"], wrong["DESCRIBE"]
+    assert wrong["DIGEST"] == small["DIGEST"]
+    assert _child({})["DIGEST"] == small["DIGEST"]      # (and the default configuration, latency path on)
 
 
 def test_engine_options_do_not_change_the_proofs():
