@@ -107,7 +107,7 @@ std::string Algorithm::describe() const {
     std::string out = buf;
     if (impl_->quotient_eval) out += std::string(" quotient=evaluation-form") + (impl_->fuse_z_digits ? "+digits" : "") + "(c: " + std::to_string(impl_->mC.nbit) + " grouped + " + std::to_string(impl_->mC.nflat - impl_->mC.nbit) + " flat + " + std::to_string(impl_->mC.nwide) + " windowed)";
     else out += " quotient=coefficient-form";
-    out += impl_->small.ok ? " witness=small-integer(" + std::to_string(impl_->small.n_levels) + " chained levels, fallbacks " + std::to_string(impl_->small_fallbacks.load()) + ")" : " witness=generic";
+    out += impl_->small.ok ? " witness=small-integer(" + std::to_string(impl_->small.n_levels) + " chained levels, fallbacks " + std::to_string(impl_->small_fallbacks.load()) + ")" : " witness=generic" + (impl_->small.why.empty() ? std::string() : "(" + impl_->small.why + ")");
     out += " served(calls/statements)=";
     const auto sv = picker_->served();
     for (size_t i = 0; i < sv.size(); i++) out += (i ? "," : "") + std::to_string(sv[i].calls) + "/" + std::to_string(sv[i].statements);
