@@ -123,6 +123,7 @@ class AlgorithmImpl {
         DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync; DevBuf<GlvSplit> d_glv;
         DevBuf<fe> d_mask, d_commit; DevBuf<G1Xyzz> d_sumD, d_sumPok;
         DevBuf<fe> d_W, d_A, d_B, d_C;
+        bool small_active = false;      // the chunk being proved left W, A, B, C as byte planes (the 32-byte matrices then only hold the rows marked wide)
         DevBuf<int8_t> d_W8, d_A8, d_B8, d_C8; DevBuf<uint32_t> d_wsflag;      // byte planes of the small-integer witness path; its "a prediction failed" flag
         DevBuf<G1Xyzz> d_part1a, d_part1b, d_sumA, d_sumB1, d_sumK, d_sumZ, d_sumC, d_tmp; DevBuf<G2Xyzz> d_part2a, d_part2b, d_sumB2;
         DevBuf<uint4> d_digits_s2; DevBuf<uint8_t> d_gok_s2;                                        // side2's digits (its partial sums are the G2 buffers, which nothing else uses)
@@ -201,7 +202,14 @@ class AlgorithmImpl {
     }
     static constexpr size_t WIN_SLICE = 256;      // bases per slice of the windowed kernel at full batches (measured 64 .. 512: kernel time within 1 %)
     bool few_solver_wanted(size_t n, size_t B) const { return n <= (size_t)cfg.few_max && B == 64 && cfg.few_solver; }
-    struct MsmCtx { hipStream_t stream; uint4* digits; uint8_t* gok; };
+    struct MsmCtx { hipStream_t stream; uint4* digits; uint8_t* gok; const int8_t* plane = nullptr; size_t plane_rows = 0, plane_stride = 0; };      // plane: the scalars' byte plane (small-integer witness path)
+    // the byte plane that stands for the scalar matrix `scalars` in the chunk this lane is proving (none: the matrix holds every row)
+    MsmCtx with_plane(MsmCtx c, const Lane& ln, const fe* scalars) const {
+        if (!ln.small_active) return c;
+        if (scalars == ln.d_W.p) { c.plane = ln.d_W8.p; c.plane_rows = n_wires; c.plane_stride = small.rows_per_group; }
+        else if (scalars == ln.d_C.p) { c.plane = ln.d_C8.p; c.plane_rows = n_constraints; c.plane_stride = n_constraints; }
+        return c;
+    }
     template <class XyzzT, class LR>
     void reduce_slices(hipStream_t st, XyzzT* pa, XyzzT* pb, size_t nslices, size_t cols, XyzzT* out, LR launch_reduce);
     // the same for the first `npr` columns of every row of `stride` (latency path: nobody reads the padding proofs' columns)

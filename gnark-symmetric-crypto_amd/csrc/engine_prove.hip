@@ -57,7 +57,7 @@ void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set
         auto part = [&](const MsmSet<AffT>& m, bool stamp) {
             if (!m.nflat) return;
             const size_t nslices = ((m.nflat + 7) / 8 + 63) / 64;
-            MsmFlatRecodeArgs ra{scalars, m.frows.p, m.octwin.p, m.nflat, B, m.cv, ctx.digits, m.nbit, m.group_ok.p, ctx.gok, wires ? 1 : 0};
+            MsmFlatRecodeArgs ra{scalars, m.frows.p, m.octwin.p, m.nflat, B, m.cv, ctx.digits, m.nbit, m.group_ok.p, ctx.gok, wires ? 1 : 0, ctx.plane, ctx.plane_rows, ctx.plane_stride};
             launch_msm_recode_flat_few(ra, n_real, ctx.stream);
             MsmFlatArgs a{m.ftable.p, m.rowoff.p, m.rowlen.p, m.nflat, ctx.digits, B, nslices, 512, pa + ns * B, m.nbit, m.sub.p, ctx.gok, scalars, m.frows.p};
             if (stamp) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
@@ -72,7 +72,7 @@ void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set
         return;
     }
     if (set.nflat) {
-        MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ctx.digits, set.nbit, set.group_ok.p, ctx.gok, wires ? 1 : 0};
+        MsmFlatRecodeArgs ra{scalars, set.frows.p, set.octwin.p, set.nflat, B, set.cv, ctx.digits, set.nbit, set.group_ok.p, ctx.gok, wires ? 1 : 0, ctx.plane, ctx.plane_rows, ctx.plane_stride};
         if (fewm) {       // (a set whose windowed part has no latency layout: GSC_FEW_WIDE=0)
             const size_t nslices = ((set.nflat + 7) / 8 + 63) / 64;
             launch_msm_recode_flat_few(ra, n_real, ctx.stream);
@@ -115,16 +115,16 @@ void AlgorithmImpl::run_msm_g1(Lane& ln, const MsmSet<G1Aff>& set, const fe* sca
     const int k = set_index(set);
     if (side) {
         if (!set.latency_flat() || B != 64) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
-        run_msm(ln, MsmCtx{ln.side, ln.d_digits_s.p, ln.d_gok_s.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1c.p, ln.d_part1d.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, false, false, ln.pending1,
+        run_msm(ln, with_plane(MsmCtx{ln.side, ln.d_digits_s.p, ln.d_gok_s.p}, ln, scalars), set, scalars, mont != 0, B, ln.n_real, ln.d_part1c.p, ln.d_part1d.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, false, false, ln.pending1,
                 launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
         return;
     }
-    run_msm(ln, MsmCtx{ln.stream, ln.d_digits_w.p && &set != &mZ ? ln.d_digits_w.p : ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, digits_ready, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
+    run_msm(ln, with_plane(MsmCtx{ln.stream, ln.d_digits_w.p && &set != &mZ ? ln.d_digits_w.p : ln.d_digits.p, ln.d_gok.p}, ln, scalars), set, scalars, mont != 0, B, ln.n_real, ln.d_part1a.p, ln.d_part1b.p, ln.d_sj1[k].p, ln.d_flat1[k].p, sum, timed, digits_ready, ln.pending1, launch_msm_flat_g1, launch_msm_flat_few_g1, launch_msm_win_g1, launch_msm_win_few_g1, launch_msm_reduce_g1, launch_msm_reduce_few_g1);
 }
 
 void AlgorithmImpl::run_msm_g2(Lane& ln, const MsmSet<G2Aff>& set, const fe* scalars, int mont, size_t B, G2Xyzz* sum, bool side) {
     if (side && (!set.latency_flat() || B != 64)) throw std::runtime_error("internal: side-stream MSM on a set with a windowed part");
-    run_msm(ln, side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits_w.p ? ln.d_digits_w.p : ln.d_digits.p, ln.d_gok.p}, set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_reduce_few_g2);
+    run_msm(ln, with_plane(side ? MsmCtx{ln.side2, ln.d_digits_s2.p, ln.d_gok_s2.p} : MsmCtx{ln.stream, ln.d_digits_w.p ? ln.d_digits_w.p : ln.d_digits.p, ln.d_gok.p}, ln, scalars), set, scalars, mont != 0, B, ln.n_real, ln.d_part2a.p, ln.d_part2b.p, ln.d_sj2.p, ln.d_flat2.p, sum, false, false, ln.pending2, launch_msm_flat_g2, launch_msm_flat_few_g2, launch_msm_win_g2, launch_msm_win_few_g2, launch_msm_reduce_g2, launch_msm_reduce_few_g2);
 }
 
 void AlgorithmImpl::fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out) {
@@ -180,6 +180,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
     // Circuits whose witness is small integers (ChaCha20-V3): the integer kernels on byte planes (wit_small.hpp) instead of the level launches
     const bool small_call = small.ok && allow_small && !latency_call && !strace;
+    ln.small_active = small_call;
     if (few_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
     SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
                      ln.d_status.p, sa.mask, sa.commit, ln.d_fsync.p, 1u << 21, 0u, n_levels, nullptr};
@@ -230,11 +231,13 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         const uint32_t per_chunk = 4 * WS_IB;
         launch_wit_rows(WitRowsArgs{ws_rtiny.p, small.n_rtiny, per_chunk, (small.n_rtiny + per_chunk - 1) / per_chunk, ws_rgen.p, small.n_rgen, ws_rtwire.p, ws_rtcoef.p, ln.d_W8.p, small.rows_per_group,
                                     ln.d_A8.p, ln.d_B8.p, ln.d_C8.p, n_constraints, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p, ln.d_wsflag.p}, B / 64, ln.stream);
-        // the byte planes as 32-byte elements for the consumers that have no byte-plane form (yet)
-        launch_wit_expand(ln.d_W8.p, small.rows_per_group, n_wires, nullptr, ln.d_W.p, B, ln.stream);
-        launch_wit_expand(ln.d_A8.p, n_constraints, n_constraints, ws_cls_a.p, ln.d_A.p, B, ln.stream);
-        launch_wit_expand(ln.d_B8.p, n_constraints, n_constraints, ws_cls_b.p, ln.d_B.p, B, ln.stream);
-        launch_wit_expand(ln.d_C8.p, n_constraints, n_constraints, ws_cls_c.p, ln.d_C.p, B, ln.stream);
+        // The consumers (first transform kernel, flat recoders) read the byte planes; the 32-byte matrices only hold the rows predicted wide.
+        if (dbg) {      // debug dumps want every row as a 32-byte element
+            launch_wit_expand(ln.d_W8.p, small.rows_per_group, n_wires, nullptr, ln.d_W.p, B, ln.stream);
+            launch_wit_expand(ln.d_A8.p, n_constraints, n_constraints, ws_cls_a.p, ln.d_A.p, B, ln.stream);
+            launch_wit_expand(ln.d_B8.p, n_constraints, n_constraints, ws_cls_b.p, ln.d_B.p, B, ln.stream);
+            launch_wit_expand(ln.d_C8.p, n_constraints, n_constraints, ws_cls_c.p, ln.d_C.p, B, ln.stream);
+        }
     } else run_levels(0, n_levels);
     if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[6], ln.stream));
     if (strace) {
@@ -276,6 +279,8 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     // 2. quotient polynomial.  Coefficient form: h overwrites A, canonical, bit-reversed order (six transforms).  Evaluation form (batch calls,
     // k_quot_bases.hip): d = A B on the zeta-coset overwrites A, natural order (four transforms); c stays where the solver wrote it.
     NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
+    const NttNarrow planes{{ln.d_A8.p, ln.d_B8.p, ln.d_C8.p}, n_constraints};
+    const NttNarrow* narrow = small_call ? &planes : nullptr;      // a, b (and c) of this chunk are byte planes
     HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
     const bool few_call = ln.n_real <= (size_t)cfg.few_max && cfg.few_path;
     const bool use_zfew = few_call && mZfew.nflat;                 // the latency layout holds the key's own Z: coefficient form
@@ -289,9 +294,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
             HIP_CHECK(launch_compute_h(plan, ta.p, tb.p, tc.p, n_constraints, B, ln.stream, 0));
             fetch_column(ln, ta.p, domain_n, B, 0, dbg->H);
         }
-        if (fuse_z_digits && !few_call) HIP_CHECK(launch_compute_d_digits(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, QuotDigits{ln.d_digits.p, mZ.c, mZ.nwin}, ln.stream));
-        else HIP_CHECK(launch_compute_d(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0));
-    } else HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0));      // latency path: the statements' columns only
+        if (fuse_z_digits && !few_call) HIP_CHECK(launch_compute_d_digits(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, QuotDigits{ln.d_digits.p, mZ.c, mZ.nwin}, ln.stream, narrow));
+        else HIP_CHECK(launch_compute_d(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0, narrow));
+    } else HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0, narrow));      // latency path: the statements' columns only
     HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
     if (dbg && !eval) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
     // 3. MSMs.  (With fuse_z_digits the digits of d are already in the lane's Z digit buffer; every other set recodes into d_digits_w.)

@@ -482,6 +482,10 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
         ln.d_W8.alloc((size_t)small.rows_per_group * B); ln.d_A8.alloc(n_constraints * B); ln.d_B8.alloc(n_constraints * B); ln.d_C8.alloc(n_constraints * B); ln.d_wsflag.alloc(1);
         HIP_CHECK(hipMemsetAsync(ln.d_W8.p, 0, ln.d_W8.n, ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_A8.p, 0, ln.d_A8.n, ln.stream));
         HIP_CHECK(hipMemsetAsync(ln.d_B8.p, 0, ln.d_B8.n, ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_C8.p, 0, ln.d_C8.n, ln.stream));
+        // rows predicted wide: their plane entries say "see the 32-byte element" for good (the rows kernel never writes them)
+        launch_wit_mark_wide(ln.d_A8.p, n_constraints, n_constraints, ws_cls_a.p, B, ln.stream); launch_wit_mark_wide(ln.d_B8.p, n_constraints, n_constraints, ws_cls_b.p, B, ln.stream);
+        launch_wit_mark_wide(ln.d_C8.p, n_constraints, n_constraints, ws_cls_c.p, B, ln.stream);
+        HIP_CHECK(hipGetLastError());
     }
     // partial-sum / digit buffers: the largest need over every batch size this context can be asked for
     size_t p1 = 0, p1b = 0, p2 = 0, p2b = 0, dg = 0, dgz = 0, sj2 = 0, gk = 0; size_t sj1[Lane::NSETS] = {0, 0, 0, 0, 0, 0, 0, 0};

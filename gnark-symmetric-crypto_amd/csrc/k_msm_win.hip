@@ -100,13 +100,29 @@ __global__ __launch_bounds__(64) void k_recode(MsmRecodeArgs a) {
 //    wire whose (base, window) pairs were laid out as bases of their own, with the points 2^(c j) P (tiny wide sets: no Horner pass).
 // FEW = false: one wave per (64 proofs, octet), o wave-uniform, gok per (octet, wave).  FEW = true (calls with a handful of statements): lanes are
 // octets of ONE proof (blockIdx.y), gok per (octet, proof): gok[o * MSM_FEW_PROOFS + p].
+// A byte-plane entry (0, 1, -1) as the Montgomery image the generic solver would have stored
+__device__ __forceinline__ fe fe_of_plane(int t) {
+    const fe one = Fr::one(), mone = Fr::neg(one);
+    fe r;
+#pragma unroll
+    for (int q = 0; q < 8; q++) r.l[q] = t > 0 ? one.l[q] : (t < 0 ? mone.l[q] : 0u);
+    return r;
+}
 template <bool FEW>
 __device__ __forceinline__ void recode_flat_octet(const MsmFlatRecodeArgs& a, size_t o, size_t p) {
     auto U = [](uint32_t v) { return FEW ? v : uni(v); };
     const int32_t win0 = a.octwin ? (int32_t)U((uint32_t)a.octwin[o]) : -1;
+    // scalar row `row` of proof p: from the byte plane when the small-integer witness path left it there (tv: its entry), else the 32-byte element
+    const int8_t* pp = a.plane ? a.plane + (p >> 6) * a.plane_stride * 64 + (p & 63) : nullptr;
+    auto load_scalar = [&](uint32_t row, int& tv) {
+        tv = (int)WS_PLANE_WIDE;
+        if (pp && row < a.plane_rows) tv = (int)pp[(size_t)row * 64];
+        return tv == (int)WS_PLANE_WIDE ? load_fe(a.scalars + (size_t)row * a.batch + p) : fe_of_plane(tv);
+    };
     uint32_t w[4] = {0, 0, 0, 0};
     if (win0 >= 0) {
-        fe s = load_fe(a.scalars + (size_t)U(a.rows[8 * o]) * a.batch + p);
+        int tv;
+        fe s = load_scalar(U(a.rows[8 * o]), tv);
         if (a.mont) s = Fr::from_mont(s);
         const bool ng = sign_normalise(s);
         const uint32_t c = (uint32_t)a.c, cmask = (1u << c) - 1, D = 1u << (c - 1);
@@ -124,11 +140,40 @@ __device__ __forceinline__ void recode_flat_octet(const MsmFlatRecodeArgs& a, si
         a.digits[o * a.batch + p] = make_uint4(w[0], w[1], w[2], w[3]);
         return;
     }
+    if (pp && a.mont) {
+        // Byte-plane rows: the values are already the small integers the recoding is after.  (Rows are wave-uniform, so is "all eight in the plane".)
+        int tv[8]; bool all_plane = true;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const size_t k = 8 * o + i;
+            const uint32_t row = k < a.nbases ? U(a.rows[k]) : 0xFFFFFFFFu;
+            tv[i] = row < a.plane_rows ? (int)pp[(size_t)row * 64] : (int)WS_PLANE_WIDE;
+            if (k >= a.nbases) tv[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) all_plane = all_plane && tv[i] != (int)WS_PLANE_WIDE;
+        if (FEW ? all_plane : (bool)__all(all_plane)) {
+            if (o < a.nbit / 8) {
+                int32_t v = 0, w3 = 1;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { v += tv[i] * w3; w3 *= 3; }
+                const bool all_ok = U(a.group_ok[o]) != 0;
+                if (FEW) a.gok[o * MSM_FEW_PROOFS + p] = all_ok ? 1 : 0;
+                else if (threadIdx.x == 0) a.gok[o * (a.batch / 64) + blockIdx.x] = all_ok ? 1 : 0;
+                if (all_ok) { a.digits[o * a.batch + p] = make_uint4((uint32_t)v & 0xFFFFu, 0, 0, 0); return; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i >> 1] |= ((uint32_t)tv[i] & 0xFFFFu) << (16 * (i & 1));
+            a.digits[o * a.batch + p] = make_uint4(w[0], w[1], w[2], w[3]);
+            return;
+        }
+    }
     fe s[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const size_t k = 8 * o + i;
-        s[i] = k < a.nbases ? load_fe(a.scalars + (size_t)U(a.rows[k]) * a.batch + p) : fe{};
+        int tv;
+        s[i] = k < a.nbases ? load_scalar(U(a.rows[k]), tv) : fe{};
     }
     if (o < a.nbit / 8) {
         const fe minus_one = Fr::neg(Fr::one());

@@ -203,10 +203,25 @@ __device__ __forceinline__ void dit_run(const Tile& t, uint32_t u4, uint32_t q, 
     for (; s < s1; s += 2) { dit_round4<STRIDED>(t, u4, q, half_of(s), s, L, Llo, tile_id, pl); __syncthreads(); }
 }
 
+// An entry of a byte plane (0, 1, -1) as the limbs of its 2^256 Montgomery image (what the generic solver stores for that value)
+__device__ __forceinline__ fe9 narrow9(int t) {
+    fe one, mone;
+#pragma unroll
+    for (int i = 0; i < 8; i++) one.l[i] = FrParams::one(i);
+    { uint64_t br = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)FrParams::mod(i) - one.l[i] - br; mone.l[i] = (uint32_t)d; br = (d >> 32) & 1; } }
+    const fe9 p1 = F::unpack(one), m1 = F::unpack(mone);
+    fe9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = t > 0 ? p1.l[i] : (t < 0 ? m1.l[i] : 0);
+    return r;
+}
+
 // K1: strided DIF head.  grid (2^Llo, batch/P, nvec); block (2^(Lhi-2) * P).  Input: the solver's a/b/c rows (canonical values of
 // the 2^256 Montgomery domain); they are used as they are — every stage is linear, and K2's scale table folds in the
 // change of domain (2^256 -> 2^261).
-__global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, size_t batch) {
+__global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe* v1, fe* v2, size_t m, size_t batch, NttNarrow nr) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int L = pl.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     const uint32_t G = 1u << Lhi;
@@ -214,9 +229,23 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
     const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
     const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
     Tile t{smem, G * P};
-    for (uint32_t e = u4; e < G; e += G / 4) {
-        const size_t idx = ((size_t)e << Llo) + g;
-        t.put(e, q, idx < m ? F::unpack(ld_stream(vec + idx * batch + q0 + q)) : F::zero());
+    const int8_t* plane = blockIdx.z == 0 ? nr.plane[0] : blockIdx.z == 1 ? nr.plane[1] : nr.plane[2];
+    if (plane) {      // (wave-uniform) the small-integer witness path left this vector as a byte plane; the few wide rows are 32-byte elements in `vec`
+        const int8_t* pp = plane + ((q0 + q) >> 6) * nr.crows * 64 + ((q0 + q) & 63);
+        for (uint32_t e = u4; e < G; e += G / 4) {
+            const size_t idx = ((size_t)e << Llo) + g;
+            fe9 x = F::zero();
+            if (idx < m) {
+                const int tv = (int)pp[idx * 64];
+                x = tv == (int)WS_PLANE_WIDE ? F::unpack(ld_stream(vec + idx * batch + q0 + q)) : narrow9(tv);
+            }
+            t.put(e, q, x);
+        }
+    } else {
+        for (uint32_t e = u4; e < G; e += G / 4) {
+            const size_t idx = ((size_t)e << Llo) + g;
+            t.put(e, q, idx < m ? F::unpack(ld_stream(vec + idx * batch + q0 + q)) : F::zero());
+        }
     }
     __syncthreads();
     dif_run<true>(t, u4, q, 0, Lhi, 0, L, Llo, g, pl, G);
@@ -370,16 +399,16 @@ __global__ __launch_bounds__(256) void k_ntt_final_contig(NttPlan pl, fe* vh, co
 }  // namespace
 
 namespace {
-hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, int eval, const QuotDigits& qd);
+hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, int eval, const QuotDigits& qd, const NttNarrow* narrow);
 }
-hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols) { return launch_quotient(p, a, b, c, m, batch, s, ncols, 0, QuotDigits{nullptr, 0, 0}); }
-hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols) { return launch_quotient(p, a, b, nullptr, m, batch, s, ncols, 1, QuotDigits{nullptr, 0, 0}); }
-hipError_t launch_compute_d_digits(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, const QuotDigits& qd, hipStream_t s) {
+hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, const NttNarrow* narrow) { return launch_quotient(p, a, b, c, m, batch, s, ncols, 0, QuotDigits{nullptr, 0, 0}, narrow); }
+hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols, const NttNarrow* narrow) { return launch_quotient(p, a, b, nullptr, m, batch, s, ncols, 1, QuotDigits{nullptr, 0, 0}, narrow); }
+hipError_t launch_compute_d_digits(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, const QuotDigits& qd, hipStream_t s, const NttNarrow* narrow) {
     if (!qd.digits || qd.c < 4 || qd.c > MSM_MAX_WINDOW || qd.nwin != msm_windows(qd.c)) return hipErrorInvalidValue;
-    return launch_quotient(p, a, b, nullptr, m, batch, s, 0, 2, qd);
+    return launch_quotient(p, a, b, nullptr, m, batch, s, 0, 2, qd, narrow);
 }
 namespace {
-hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, int eval, const QuotDigits& qd) {
+hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols, int eval, const QuotDigits& qd, const NttNarrow* narrow) {
     const int L = p.L, Lhi = (L + 1) / 2, Llo = L - Lhi;
     if (L < NTT_MIN_LOG2 || L > NTT_MAX_LOG2 || batch % P) return hipErrorInvalidValue;      // block sizes / launch bounds below assume this range
     const unsigned G = 1u << Lhi, Cn = 1u << Llo;
@@ -393,7 +422,8 @@ hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size
     opt_in(eval == 2 ? reinterpret_cast<const void*>(k_ntt_pointwise_strided<2>) : eval ? reinterpret_cast<const void*>(k_ntt_pointwise_strided<1>) : reinterpret_cast<const void*>(k_ntt_pointwise_strided<0>), lds_s);
     opt_in(reinterpret_cast<const void*>(k_ntt_mid_contig), lds_c); opt_in(reinterpret_cast<const void*>(k_ntt_final_contig), lds_c);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, eval ? 2 : 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch);
+    const NttNarrow nr = narrow ? *narrow : NttNarrow{{nullptr, nullptr, nullptr}, 0};
+    hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, eval ? 2 : 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch, nr);
     hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 2), dim3(Cn / 4 * P), lds_c, s, p, a, b, c, batch);
     if (eval == 2) { hipLaunchKernelGGL(k_ntt_pointwise_strided<2>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch, qd); return hipGetLastError(); }
     if (eval) { hipLaunchKernelGGL(k_ntt_pointwise_strided<1>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch, qd); return hipGetLastError(); }

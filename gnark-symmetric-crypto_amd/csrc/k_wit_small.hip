@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256) void k_wit_expand(const int8_t* __restrict__ p
     store_fe(mat + row * batch + p, v);
 }
 
+__global__ __launch_bounds__(256) void k_wit_mark_wide(int8_t* __restrict__ plane, size_t rows_per_group, size_t nrows, const uint8_t* __restrict__ cls, size_t batch) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nrows * batch) return;
+    const size_t row = idx / batch, p = idx % batch;
+    if (cls[row]) plane[((p >> 6) * rows_per_group + row) * 64 + (p & 63)] = WS_PLANE_WIDE;
+}
+
 // The input wires (written as 32-byte elements by k_assign_*) into the byte plane: rows 0 .. nrows-1; anything but 0, 1, -1 raises the flag
 __global__ __launch_bounds__(256) void k_wit_narrow(const fe* __restrict__ W, size_t batch, size_t nrows, int8_t* __restrict__ W8, size_t rows_per_group, uint32_t* __restrict__ flag) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -227,6 +234,11 @@ void launch_wit_expand(const int8_t* plane, size_t rows_per_group, size_t nrows,
     const size_t n = nrows * batch;
     if (!n) return;
     hipLaunchKernelGGL(k_wit_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, plane, rows_per_group, nrows, cls, mat, batch);
+}
+void launch_wit_mark_wide(int8_t* plane, size_t rows_per_group, size_t nrows, const uint8_t* cls, size_t batch, hipStream_t s) {
+    const size_t n = nrows * batch;
+    if (!n) return;
+    hipLaunchKernelGGL(k_wit_mark_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, plane, rows_per_group, nrows, cls, batch);
 }
 void launch_wit_narrow(const fe* W, size_t batch, size_t nrows, int8_t* W8, size_t rows_per_group, uint32_t* flag, hipStream_t s) {
     const size_t n = nrows * batch;

@@ -97,6 +97,8 @@ struct WitRowsArgs {
     uint32_t* status; uint32_t* flag;
 };
 void launch_wit_rows(const WitRowsArgs& a, size_t groups, hipStream_t s);
+// plane[(group * rows_per_group + row) * 64 + lane] = WS_PLANE_WIDE for every row with cls[row] != 0 (once per lane buffer: nothing else writes those entries)
+void launch_wit_mark_wide(int8_t* plane, size_t rows_per_group, size_t nrows, const uint8_t* cls, size_t batch, hipStream_t s);
 // mat[row * batch + p] = the plane's value as a Montgomery element, for rows 0 .. nrows-1 (cls != nullptr: only rows with cls[row] == 0)
 void launch_wit_expand(const int8_t* plane, size_t rows_per_group, size_t nrows, const uint8_t* cls, fe* mat, size_t batch, hipStream_t s);
 // rows 0 .. nrows-1 of W (32-byte elements: the input wires as k_assign_* wrote them) into the byte plane; a value outside {-1, 0, 1} raises *flag
@@ -109,6 +111,10 @@ void launch_coeff_small(const fe* coeff, size_t n, long long* out, uint8_t* ok, 
 void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint32_t* status, uint8_t* cls, hipStream_t s);
 
 // ---- quotient polynomial (k_ntt.hip) ----
+// Byte planes of the small-integer witness path as inputs of the first transform kernel: plane[k] (or nullptr) for vector k = a, b, c;
+// an entry 0, 1, -1 stands for that value (its 2^256 Montgomery image), WS_PLANE_WIDE says the row's 32-byte element is in the vector itself.
+constexpr int8_t WS_PLANE_WIDE = -128;
+struct NttNarrow { const int8_t* plane[3]; size_t crows; };      // plane[(group * crows + row) * 64 + lane]
 struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* half_c; const int32_t* qr; };   // tw_*, qr: 12 int32 per entry (limbs)
 constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_QMAX .. NTT_QMAX (range reduction by the top limb)
 // a,b,c: [n][batch] Montgomery, first m rows valid (rows >= m are treated as zero and need not be initialised), c = a*b row by row
@@ -118,16 +124,16 @@ constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_
 constexpr int NTT_MIN_LOG2 = 15, NTT_MAX_LOG2 = 17;
 // Returns the first launch-configuration error (nothing is launched when the domain is unsupported).
 // ncols > 0: only the first ncols columns (rounded up to the tile's 4) are transformed — a call with a handful of statements in a 64-column batch
-hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols = 0);
+hipError_t launch_compute_h(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size_t batch, hipStream_t s, size_t ncols = 0, const NttNarrow* narrow = nullptr);
 // The quotient in EVALUATION form: only the four transforms of a and b; on return a[i] = A(zeta w^i) B(zeta w^i) * 2^261 mod r as a
 // canonical integer, natural order (b overwritten, c not touched): the scalars of the bases V_i of launch_quot_bases.
-hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols = 0);
+hipError_t launch_compute_d(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, hipStream_t s, size_t ncols = 0, const NttNarrow* narrow = nullptr);
 // The same, but the last kernel recodes d itself: it writes the signed c-bit digits of the windowed MSM (launch_msm_win_g1's format, see
 // launch_msm_recode) instead of d — no scalar vector in memory, no recoding pass.  A thread of that kernel holds d at four indices, which
 // become four consecutive bases: table position t of the MSM set belongs to the index quot_digit_index(L, t) (the engine lays the bases
 // V out in that order).  Whole batches only (ncols = 0).
 struct QuotDigits { uint4* digits; int c, nwin; };
-hipError_t launch_compute_d_digits(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, const QuotDigits& qd, hipStream_t s);
+hipError_t launch_compute_d_digits(const NttPlan& p, fe* a, fe* b, size_t m, size_t batch, const QuotDigits& qd, hipStream_t s, const NttNarrow* narrow = nullptr);
 inline uint32_t quot_digit_index(int L, uint32_t t) {
     const int Lhi = (L + 1) / 2, Llo = L - Lhi; const uint32_t quarter = (1u << Lhi) / 4;
     const uint32_t kq = t & 3, m = t >> 2, u4 = m % quarter, g = m / quarter;
@@ -222,6 +228,9 @@ struct MsmFlatRecodeArgs {
     uint4* digits;
     size_t nbit; const uint8_t* group_ok; uint8_t* gok;
     int mont;                                       // scalars are Montgomery values (wires) or canonical integers (h)
+    // byte plane of the small-integer witness path (or nullptr): a scalar row r < plane_rows is read from plane[(group * plane_stride + r) * 64 + lane]
+    // (0, 1, -1; WS_PLANE_WIDE = the row's 32-byte element is in `scalars` after all) instead of scalars[r * batch + p]
+    const int8_t* plane = nullptr; size_t plane_rows = 0, plane_stride = 0;
 };
 void launch_msm_recode_flat(const MsmFlatRecodeArgs& a, hipStream_t s);
 // lanes = octets of one proof; gok[octet * MSM_FEW_PROOFS + proof]; pairs with launch_msm_flat_few_* (nslices = ceil(octets / 64))
