@@ -59,11 +59,54 @@ def pmc_traffic(kernel_tag, batch, engine_desc):
         try:
             d = json.load(open(path))
             c = d["config"]
-            if c.get("kernel", "") == kernel_tag and c["batch"] == batch and ("window_z=%d " % c["window_z"]) in engine_desc:
+            # the profile must be of THIS kernel configuration: algorithm, batch, digit width, number of bases and the quotient form
+            # (evaluation form walks the n bases V, coefficient form the n - 1 of the key) — a profile that does not say is not replayed
+            if c.get("kernel", "") == kernel_tag and c["batch"] == batch and ("window_z=%d " % c["window_z"]) in engine_desc \
+                    and c.get("quotient") and ("quotient=%s" % c["quotient"]) in engine_desc and ("Z=%d " % c.get("nbases", -1)) in engine_desc:
                 return d["hbm_bytes_per_launch"], "replayed from %s (rocprofv3 PMC passes of this configuration; counters cannot be read inside the timed run)" % os.path.relpath(path, ROOT)
         except Exception:
             pass
     return None, None
+
+
+def valu_per_wave_add():
+    """VALU instructions the Z-table kernel issues per wave-addition (64 lanes x one mixed addition), from the newest committed SQ counter
+    pass (profiles/r*_valu_per_add*.json, made by tools/make_valu_per_add.py from SQ_INSTS_VALU of the kernel): a property of the kernel's
+    code, replayed like `traffic` because counters cannot be read inside the timed run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_per_add*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            return float(d["instr_per_wave_add"]), "replayed from %s (SQ_INSTS_VALU / wave-additions of a rocprofv3 --pmc pass)" % os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return None, None
+
+
+# VALU-only time of the Z kernel per digit window at 8192 columns: the launch with every gather forced onto one table entry (no misses) took
+# 15.4 ms per window at c = 13 and at c = 16 alike (profiles/r02_window_sweep.txt, DESIGN.md 3.4); it scales with the columns.
+VALU_ONLY_MS_PER_WINDOW_8192 = 15.4
+WAVE64_ISSUE_CYCLES = 4.0      # a wave64 VALU instruction occupies a 16-lane SIMD for four cycles: the issue floor
+
+
+def roofline_valu_of(roof, rows, simds):
+    """The BINDING roofline of the Z-table kernel: VALU issue.  cycles per wave instruction = launch time x shader clock x SIMDs /
+    (instructions per wave-addition x wave-additions); frac = 4 / that.  Clock: measured live by the kernel itself (two clock stamps of
+    a wave in the middle of the launch, gsc_last_kernel_clock); instruction count: replayed from the committed counter pass."""
+    clocks = [r[6] for r in rows if r[6] > 0]; nwin = rows[-1][7]; cols, nb = rows[-1][3], rows[-1][4]
+    ipa, src = valu_per_wave_add()
+    if not clocks or not ipa or not nwin or not simds:
+        return None
+    mhz = sum(clocks) / len(clocks); ms = roof["launch_ms"]
+    wave_adds = nb * nwin * (cols // 64)
+    cpi = ms * 1e-3 * mhz * 1e6 * simds / (ipa * wave_adds)
+    valu_ms = nwin * VALU_ONLY_MS_PER_WINDOW_8192 * cols / 8192.0
+    return {"kernel": roof["kernel"], "bound": "valu-issue", "instr_per_wave_add": ipa, "instr_source": src,
+            "wave_adds_per_launch": wave_adds, "windows": nwin, "simds": simds, "clock_mhz": round(mhz, 1),
+            "clock_source": "live: shader-clock / 100 MHz-clock stamps of one wave in the middle of each timed launch, averaged",
+            "launch_ms": ms, "cycles_per_wave_instr": round(cpi, 4), "issue_floor_cycles": WAVE64_ISSUE_CYCLES, "frac": round(WAVE64_ISSUE_CYCLES / cpi, 4),
+            "valu_only_ms": round(valu_ms, 2), "valu_only_source": "%.1f ms per window at 8192 columns with every gather forced onto one entry (profiles/r02_window_sweep.txt), scaled by the columns" % VALU_ONLY_MS_PER_WINDOW_8192,
+            "miss_clock_loss_ms": round(ms - valu_ms, 2)}
 
 
 XOSHIRO_SEED = 0x9E3779B97F4A7C15
@@ -101,11 +144,13 @@ def synthetic_records(n, seed):
     return xoshiro_records(n, int(seed) << 32)
 
 
-def engine_env(workload, per_algo, share=1):
+def engine_env(workload, per_algo, share=1, library_defaults=False):
     """The engine configuration a timed run uses (environment read by libprove at InitAlgorithm).  One place, so that the test of the
-    timed configuration (tests/test_gpu_00_bench_config.py) starts its prover with exactly these settings."""
+    timed configuration (tests/test_gpu_00_bench_config.py) starts its prover with exactly these settings.  library_defaults: only the
+    batch capacity is set — the table budgets stay the library's own (48 + 16 GB per algorithm: all three algorithms co-resident), the
+    multi-tenant configuration; the default run gives ONE algorithm the device."""
     env = {"GSC_MAX_BATCH": str(max(64, (per_algo + 63) // 64 * 64))}
-    if workload != "mixed":      # one algorithm alone on the device: widest Z digits that fit (ChaCha c = 17: 137 GB; AES c = 15: 137 GB); mixed keeps the
+    if workload != "mixed" and not library_defaults:      # one algorithm alone on the device: widest Z digits that fit (ChaCha c = 17: 137 GB; AES c = 15: 137 GB); mixed keeps the
         env["GSC_Z_TABLE_GB"] = str(140 // share)      # library defaults, under which all three algorithms are resident at once (3 x (48 + 16) GB)
         env["GSC_W_TABLE_GB"] = str(56 // share)       # AES-V2 wide wires (and the wide rows of c, evaluation-form quotient): c = 15 (48 GB) instead of 14
         # share > 1: several engine replicas on ONE device (the one-GPU rehearsal of --in-library --devices 0,0) split its memory
@@ -346,6 +391,7 @@ def main():
                                                                "what a single FFI host (Go / node) would do; one call of N x batch statements per step")
     ap.add_argument("--devices", default="", help="with --in-library: the device list itself (e.g. 0,0 rehearses two replicas on a one-GPU box)")
     ap.add_argument("--callers", type=int, default=2, help="concurrent caller threads that keep the library busy (each owns output buffers); small batches need several in flight")
+    ap.add_argument("--library-defaults", action="store_true", help="no table-budget overrides: the library's default (multi-tenant) configuration, under which all three circuits fit the device together")
     ap.add_argument("--stub-prover", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -380,7 +426,7 @@ def main():
     names = ["chacha20", "aes128", "aes256"] if workload == "mixed" else [workload]
     per_algo = B if workload != "mixed" else (B + 2) // 3
     share = max(devices.count(d) for d in devices) if args.in_library else 1
-    for k, v in engine_env(workload, per_algo, share).items():
+    for k, v in engine_env(workload, per_algo, share, args.library_defaults).items():
         os.environ.setdefault(k, v)
     import torch
     import torch.distributed as dist
@@ -437,8 +483,10 @@ def main():
     last_json = {}
 
     def kernel_stats(n):
+        # (the library reports the CALLING thread's own last call: with several callers a step's row is that step's, not a neighbour's)
         kname, ms, stmts, cols, nb = g.last_dominant_kernel(ALGOS[n][0])
-        return (n, (kname, ms, stmts, cols, nb), g.last_stage_ms(ALGOS[n][0]))
+        mhz, nwin = g.last_kernel_clock(ALGOS[n][0])
+        return (n, (kname, ms, stmts, cols, nb, mhz, nwin), g.last_stage_ms(ALGOS[n][0]))
 
     def prove(i, slot):
         free[slot].wait(); free[slot].clear()
@@ -551,7 +599,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fr/Fp, 254-bit modular integers)",
             "data": "synthetic",
             "config": {"workload": "%s; 1xMI355X per rank: batch of %d independent proofs per GPU per step, CSPRNG (r,s); statements from xoshiro256** seeded 0x9E3779B97F4A7C15 + index" % (desc, B),
-                       "batch_per_gpu": B, "callers": NC, "parallelism": par,
+                       "batch_per_gpu": B, "callers": NC, "parallelism": par, "tables": "library defaults (multi-tenant)" if args.library_defaults else "single algorithm per device" if workload != "mixed" else "library defaults (multi-tenant)",
                        "engine": {n: g.describe(ALGOS[n][0]) for n in names} if g else "stub"},
             "verified": verified,
         }
@@ -559,11 +607,15 @@ def main():
             # dominant kernel of the algorithm whose launch is longest; averaged over the timed steps
             per = {}
             for st in stats:
-                for n, (kname, ms, stmts, cols, nb), stage in st:
-                    per.setdefault(n, []).append((kname, ms, stmts, cols, nb, stage))
+                for n, (kname, ms, stmts, cols, nb, mhz, nwin), stage in st:
+                    per.setdefault(n, []).append((kname, ms, stmts, cols, nb, stage, mhz, nwin))
             roofs = {n: roofline_of(n, rows, g) for n, rows in per.items()}
             dom = max(roofs, key=lambda n: roofs[n]["launch_ms"])
             line["roofline"] = dict(roofs[dom])
+            if not roofs[dom]["kernel"].startswith("k_solver"):
+                rv = roofline_valu_of(roofs[dom], per[dom], 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count)
+                if rv:
+                    line["roofline_valu"] = rv
             bpp = BYTES_PER_PROOF[workload] if workload != "mixed" else sum(BYTES_PER_PROOF.values()) / 3.0
             line["roofline"]["whole_path_frac"] = round(value / ngpu * bpp / 1e9 / HBM_PEAK_GBS, 6)
             line["msm_stage"] = line["roofline"].pop("msm_stage")

@@ -20,7 +20,7 @@ CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
 ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
 
 EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw", "gsc_setup",
-           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_dominant_kernel", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_compute_d", "gsc_debug_glv_split"]
+           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_dominant_kernel", "gsc_last_kernel_clock", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_compute_d", "gsc_debug_secret_residue", "gsc_debug_glv_split"]
 
 
 class GoSlice(C.Structure):
@@ -68,6 +68,8 @@ def lib():
         L.gsc_last_stage_ms.argtypes = [C.c_ubyte, C.POINTER(C.c_float)]
         L.gsc_last_dominant_kernel.restype = C.c_int
         L.gsc_last_dominant_kernel.argtypes = [C.c_ubyte, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.gsc_last_kernel_clock.restype = C.c_int
+        L.gsc_last_kernel_clock.argtypes = [C.c_ubyte, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.gsc_debug_field_ops.restype = C.c_int
         L.gsc_debug_field_ops.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int]
         L.enforce_binding()
@@ -201,6 +203,21 @@ def last_dominant_kernel(algorithm_id: int):
     if lib().gsc_last_dominant_kernel(algorithm_id, name, 96, C.byref(ms), C.byref(st), C.byref(cols), C.byref(nb)) != 0:
         return None
     return name.value.decode(), float(ms.value), st.value, cols.value, nb.value
+
+
+def debug_secret_residue(algorithm_id: int) -> int:
+    """TEST HOOK: bytes of a finished call's secrets still non-zero in device memory (0 expected; -1: hooks disabled / error)."""
+    lib().gsc_debug_secret_residue.restype = C.c_longlong
+    lib().gsc_debug_secret_residue.argtypes = [C.c_ubyte]
+    return int(lib().gsc_debug_secret_residue(algorithm_id))
+
+
+def last_kernel_clock(algorithm_id: int):
+    """(shader clock in MHz during the last batch's Z-table kernel — 0.0 when not measured —, digit windows of the Z set)."""
+    mhz, nwin = C.c_float(0), C.c_int(0)
+    if lib().gsc_last_kernel_clock(algorithm_id, C.byref(mhz), C.byref(nwin)) != 0:
+        return None
+    return float(mhz.value), int(nwin.value)
 
 
 def last_msm_z_kernel(algorithm_id: int):

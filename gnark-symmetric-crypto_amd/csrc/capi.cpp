@@ -78,13 +78,18 @@ class Batcher {
                 while (!q_.empty() && take.size() < want) { take.push_back(q_.front()); q_.pop_front(); }
                 sched_.started(take.size());
             }
-            std::vector<ProofRequest> reqs(take.size()); std::vector<ProofResult> res(take.size());
-            for (size_t i = 0; i < take.size(); i++) reqs[i] = *take[i]->req;
-            std::string err;
-            try { algo_->prove_batch(reqs.data(), reqs.size(), res.data()); } catch (const std::exception& e) { err = e.what(); }
+            // Whatever happens below — a device error, an allocation failure, anything thrown — the callers parked on done_cv_ are released
+            // and the scheduler hears of the completion: nobody is left waiting on a batch that died.
+            std::string err; std::vector<ProofResult> res;
+            try {
+                std::vector<ProofRequest> reqs(take.size()); res.resize(take.size());
+                for (size_t i = 0; i < take.size(); i++) reqs[i] = *take[i]->req;
+                algo_->prove_batch(reqs.data(), reqs.size(), res.data(), nullptr, true);      // whole: one device batch on ONE replica (plan_shares)
+            } catch (const std::exception& e) { err = e.what(); if (err.empty()) err = "proving failed"; }
+            catch (...) { err = "proving failed (unknown error)"; }
             {
                 std::lock_guard<std::mutex> l(mu_);
-                for (size_t i = 0; i < take.size(); i++) { *take[i]->res = res[i]; take[i]->error = err; take[i]->done = true; }
+                for (size_t i = 0; i < take.size(); i++) { if (err.empty() && i < res.size()) *take[i]->res = res[i]; take[i]->error = err; take[i]->done = true; }
                 sched_.completed(take.size());
             }
             done_cv_.notify_all();
@@ -156,7 +161,11 @@ bool ascii_fold_eq(const std::string& a, const char* b) {
     return true;
 }
 
-struct Decoded { std::string cipher; std::vector<uint8_t> key, nonce, input; uint32_t counter = 0; };
+struct Decoded {
+    std::string cipher; std::vector<uint8_t> key, nonce, input; uint32_t counter = 0;
+    Decoded() = default; Decoded(Decoded&&) = default; Decoded& operator=(Decoded&&) = default; Decoded(const Decoded&) = delete; Decoded& operator=(const Decoded&) = delete;
+    ~Decoded() { if (!key.empty()) explicit_bzero(key.data(), key.size()); }      // the decoded key does not linger on the heap
+};
 
 // encoding/json semantics for InputParams (provers.go:53-59): case-insensitive keys, unknown keys ignored, the first
 // type error is remembered while decoding continues, []uint8 from base64 string / null / array of 0..255.
@@ -220,7 +229,7 @@ Decoded decode_params(const JsonValue& root) {
 
 // length checks of provers.go:81-89 / :174-182 (log.Panicf -> string panic), then the native cipher
 ProofRequest make_request(int cipher, const Decoded& d) {
-    ProofRequest q; memset(&q, 0, sizeof q);
+    ProofRequest q{};
     if (cipher == CHACHA20) { if (d.key.size() != 32) panic_string("key length must be 32: " + std::to_string(d.key.size())); }
     else if (d.key.size() != 32 && d.key.size() != 16) panic_string("key length must be 16 or 32: " + std::to_string(d.key.size()));
     if (d.nonce.size() != 12) panic_string("nonce length must be 12: " + std::to_string(d.nonce.size()));
@@ -337,7 +346,7 @@ struct Prove_return ProveBatch(GoSlice params) {
                 if (reqs.empty()) return;
                 std::vector<ProofResult> res(reqs.size());
                 Batcher* b = reqs.size() <= Batcher::SMALL_CALL ? batcher(c) : nullptr;
-                if (b) b->submit_many(reqs.data(), reqs.size(), res.data());      // a small group shares device batches with concurrent callers
+                if (b) { if (Algorithm* al = lookup((GoUint8)c)) al->forget_thread_stat(); b->submit_many(reqs.data(), reqs.size(), res.data()); }      // a small group shares device batches with concurrent callers
                 else lookup(c)->prove_batch(reqs.data(), reqs.size(), res.data());
                 for (size_t k = 0; k < reqs.size(); k++) results[idx[k]] = res[k].status ? std::string("{}") : success_json(res[k], reqs[k].ciphertext);
             } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
@@ -367,7 +376,7 @@ long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<ProofRequest> reqs(n); std::vector<ProofResult> res(n);
         for (size_t i = 0; i < n; i++) {
-            const uint8_t* rec = inputs + 112 * i; ProofRequest& q = reqs[i]; memset(&q, 0, sizeof q);
+            const uint8_t* rec = inputs + 112 * i; ProofRequest& q = reqs[i]; q = ProofRequest{};
             q.keylen = cipher == AES_128 ? 16 : 32; memcpy(q.key, rec, q.keylen); memcpy(q.nonce, rec + 32, 12);
             q.counter = (uint32_t)rec[44] | ((uint32_t)rec[45] << 8) | ((uint32_t)rec[46] << 16) | ((uint32_t)rec[47] << 24);
             memcpy(q.plaintext, rec + 48, 64);
@@ -377,7 +386,7 @@ long long gsc_prove_raw(GoUint8 cipher, const uint8_t* inputs, size_t n, uint8_t
         }
         const auto t1 = std::chrono::steady_clock::now();
         Batcher* b = n && n <= Batcher::SMALL_CALL ? batcher(cipher) : nullptr;
-        if (b) b->submit_many(reqs.data(), n, res.data());      // a small call shares device batches with concurrent callers
+        if (b) { a->forget_thread_stat(); b->submit_many(reqs.data(), n, res.data()); }      // a small call shares device batches with concurrent callers
         else a->prove_batch(reqs.data(), n, res.data());
         const auto t2 = std::chrono::steady_clock::now();
         if (trace) fprintf(stderr, "gsc_prove_raw: prepare %.2f ms, prove_batch %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
@@ -453,6 +462,11 @@ long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t* abc_be, size_t
     catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
 }
 
+long long gsc_debug_secret_residue(GoUint8 algorithmID) {
+    if (hooks_refused("gsc_debug_secret_residue") || algorithmID > 2) return -1;
+    Algorithm* a = lookup(algorithmID); if (!a) return -1;
+    try { return (long long)a->debug_secret_residue(); } catch (const std::exception& e) { fprintf(stderr, "gsc_debug_secret_residue: %s\n", e.what()); return -1; }
+}
 long long gsc_debug_compute_d(GoUint8 algorithmID, const uint8_t* ab_be, size_t m, uint8_t* d_out, size_t cap) {
     if (hooks_refused("gsc_debug_compute_d") || algorithmID > 2) return -1;
     Algorithm* a = lookup(algorithmID); if (!a) return -1;
@@ -477,6 +491,14 @@ int gsc_last_dominant_kernel(GoUint8 algorithmID, char* name, size_t cap, float*
     if (statements) *statements = st.statements;
     if (columns) *columns = st.columns;
     if (nbases) *nbases = st.nbases;
+    return 0;
+}
+int gsc_last_kernel_clock(GoUint8 algorithmID, float* clock_mhz, int* windows) {
+    if (algorithmID > 2) return -1;
+    Algorithm* a = lookup(algorithmID); if (!a) return -1;
+    const KernelStat st = a->last_kernel_stat();
+    if (clock_mhz) *clock_mhz = st.clock_mhz;
+    if (windows) *windows = st.nwin;
     return 0;
 }
 int gsc_last_stage_ms(GoUint8 algorithmID, float out[4]) {

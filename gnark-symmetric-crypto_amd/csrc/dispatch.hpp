@@ -43,6 +43,22 @@ class ReplicaPicker {
     std::vector<Counters> served_;
 };
 
+// How a call of n statements is spread over `replicas` engine replicas (Algorithm::prove_batch):
+//   * one replica, a call of up to one 64-column batch, or a batch the micro-batcher took for ONE device (whole = true) that fits a
+//     replica's capacity: ONE share, sent whole to the least-loaded replica (pick = true) — the scheduler already shared the queue out
+//     per free device, so splitting such a batch again would put several small device batches where one was meant;
+//   * anything else: contiguous shares of ceil(n / replicas) statements rounded up to whole 64-column batches, replica d takes
+//     [d * share, ...) — the last share may be ragged, replicas beyond the end of the call get nothing; every statement is in exactly one share.
+struct CallShare { size_t replica, off, n; bool pick; };
+inline std::vector<CallShare> plan_shares(size_t n, size_t replicas, size_t replica_cap, bool whole) {
+    std::vector<CallShare> out;
+    if (!n) return out;
+    if (replicas <= 1 || n <= 64 || (whole && n <= replica_cap)) { out.push_back(CallShare{0, 0, n, true}); return out; }
+    const size_t share = ((n + replicas - 1) / replicas + 63) / 64 * 64;
+    for (size_t d = 0; d < replicas && d * share < n; d++) out.push_back(CallShare{d, d * share, n - d * share < share ? n - d * share : share, false});
+    return out;
+}
+
 // How many of `queued` single-proof callers a batcher worker takes when `free_devices` devices (at least one) have no batch of the
 // algorithm on them: the queue is shared out over the free devices, so that a burst of callers spreads over every replica; on one
 // device everything goes out as ONE batch (the device time per statement falls with the batch: 2.65 ms for one, 0.40 ms at 16,

@@ -49,7 +49,7 @@ EngineConfig config_from_env() {
     if (c.small_witness < 0 || c.small_witness > 2 || (c.small_witness == 2 && !test_hooks_enabled())) throw std::runtime_error("GSC_SMALL_WITNESS must be 0 or 1");
     if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");
     c.trace_host = getenv("GSC_TRACE_HOST") != nullptr;
-    if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; }
+    if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; c.keep_secrets = getenv("GSC_KEEP_SECRETS") != nullptr; }
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
     if ((c.window_z && (c.window_z < 4 || c.window_z > MSM_MAX_WINDOW)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_Z must be in [4,17], GSC_WINDOW_W in [4,16]");
@@ -91,7 +91,9 @@ Cipher Algorithm::cipher() const { return impls_[0]->cipher; }
 size_t Algorithm::max_batch() const { size_t c = 0; for (auto& i : impls_) c += i->cap; return c; }
 size_t Algorithm::devices() const { return impls_.size(); }
 size_t Algorithm::lanes() const { return impls_[0]->lanes.size(); }      // full + small: device batches that can be in flight per device
+namespace { thread_local KernelStat t_call_stat; thread_local const Algorithm* t_call_owner = nullptr; }
 KernelStat Algorithm::last_kernel_stat() const {
+    if (t_call_owner == this) return t_call_stat;      // this thread's own last call
     AlgorithmImpl* a = impls_[last_replica_.load() < impls_.size() ? last_replica_.load() : 0].get();
     std::lock_guard<std::mutex> lk(a->stat_mu);
     return a->last_stat;
@@ -151,7 +153,7 @@ void Algorithm::debug_compute_d(const uint8_t* ab_be, size_t m, uint8_t* d_out) 
 // chunks, each on whichever lane is free.  A call with at least 2 * min_split statements that is alone on the replica is cut into as
 // many chunks as there are lanes (the latency-bound witness stage of one chunk hides under the kernels of the other); when other
 // calls are in flight it stays whole and the overlap happens between calls instead (measured on AES-128, two callers: +4 %).
-static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
+static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first, KernelStat* stat, std::mutex* stat_mu) {
     if (!n) return;
     const size_t nl = a.full_lanes, lane_cap = a.lanes[0]->cap;      // only full lanes take the chunks of a big call
     size_t nchunks = (n + lane_cap - 1) / lane_cap;
@@ -171,6 +173,7 @@ static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t 
                 const size_t off = c * chunk, take = n - off < chunk ? n - off : chunk;
                 struct Hold { AlgorithmImpl& a; size_t i; ~Hold() { a.release_lane(i); } } hold{a, a.acquire_lane(-1, take)};
                 a.prove_chunk(*a.lanes[hold.i], reqs + off, take, results + off, off == 0 ? debug_first : nullptr);
+                if (stat) { std::lock_guard<std::mutex> g(*stat_mu); if (a.lanes[hold.i]->stat.ms >= stat->ms) *stat = a.lanes[hold.i]->stat; }      // the call's chunk with the longest dominant kernel
             }
         } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
     };
@@ -181,31 +184,31 @@ static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t 
     for (auto& t : th) t.join();
     if (err) std::rethrow_exception(err);
 }
-void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first) {
+size_t Algorithm::debug_secret_residue() { size_t n = 0; for (auto& i : impls_) n += i->secret_residue(); return n; }
+void Algorithm::forget_thread_stat() const { if (t_call_owner == this) t_call_owner = nullptr; }
+void Algorithm::prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first, bool whole) {
     if (!n) return;
-    const size_t nd = impls_.size();
     struct Held { ReplicaPicker& p; size_t i, n; std::atomic<size_t>& last; ~Held() { p.release(i, n); last.store(i); } };
-    if (nd == 1 || n <= 64) {
-        // A call of up to one 64-column batch is not split: it goes, whole, to the least-loaded replica (ReplicaPicker) — concurrent
-        // single-proof callers and the micro-batcher's small batches therefore use every GPU of the node, not only the first one.
+    KernelStat call_stat; std::mutex call_stat_mu;
+    struct Publish { const Algorithm* self; KernelStat& st; ~Publish() { t_call_stat = st; t_call_owner = self; } } publish{this, call_stat};
+    const std::vector<CallShare> shares = plan_shares(n, impls_.size(), impls_[0]->cap, whole);
+    if (shares.size() == 1 && shares[0].pick) {
+        // not split: the call goes, whole, to the least-loaded replica (ReplicaPicker) — concurrent single-proof callers and the
+        // micro-batcher's batches therefore use every GPU of the node, not only the first one.
         Held h{*picker_, picker_->acquire(n), n, last_replica_};
-        return prove_on_replica(*impls_[h.i], reqs, n, results, debug_first);
+        return prove_on_replica(*impls_[h.i], reqs, n, results, debug_first, &call_stat, &call_stat_mu);
     }
     // Proofs are independent: contiguous shares (multiples of 64) go to the replicas, one host thread per device; nothing is
     // exchanged between devices (the "gather" is the results array the threads fill).
-    size_t share = ((n + nd - 1) / nd + 63) / 64 * 64;
     std::exception_ptr err; std::mutex err_mu; std::vector<std::thread> th;
-    auto work = [&](size_t d) {
-        const size_t off = d * share;
-        if (off >= n) return;
-        const size_t take = n - off < share ? n - off : share;
-        picker_->acquire_on(d, take);
-        Held h{*picker_, d, take, last_replica_};
-        try { prove_on_replica(*impls_[d], reqs + off, take, results + off, d == 0 ? debug_first : nullptr); }
+    auto work = [&](const CallShare& sh) {
+        picker_->acquire_on(sh.replica, sh.n);
+        Held h{*picker_, sh.replica, sh.n, last_replica_};
+        try { prove_on_replica(*impls_[sh.replica], reqs + sh.off, sh.n, results + sh.off, sh.off == 0 ? debug_first : nullptr, &call_stat, &call_stat_mu); }
         catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
     };
-    for (size_t d = 1; d < nd; d++) th.emplace_back(work, d);
-    work(0);
+    for (size_t k = 1; k < shares.size(); k++) th.emplace_back(work, shares[k]);
+    work(shares[0]);
     for (auto& t : th) t.join();
     if (err) std::rethrow_exception(err);
 }

@@ -5,6 +5,7 @@
 // to HBM and builds the fixed-base tables; "Prove" runs the device pipeline for a batch of independent proofs.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <atomic>
 #include <cstddef>
 #include <memory>
@@ -21,6 +22,8 @@ struct ProofRequest {
     uint8_t plaintext[64];
     uint8_t ciphertext[64];          // filled by the caller with the native cipher
     uint8_t r[32], s[32], mask[32];  // prover randomness, canonical little-endian, < r
+    // every copy of a request (the callers', the micro-batcher's, the staging vectors) clears its key and randomness when it goes away
+    ~ProofRequest() { explicit_bzero(this, sizeof *this); }
 };
 struct ProofResult {
     int status = 0;                  // 0 ok; 1 unsatisfied constraint system; 2 degenerate point
@@ -55,6 +58,7 @@ struct EngineConfig {
     bool trace_host = false;     // GSC_TRACE_HOST: host-side timing lines on stderr (InitAlgorithm breakdown, per-chunk enqueue / wait / serialise)
     // diagnostics that change what the device does: honoured only when the test hooks were enabled at load time (test_hooks_enabled())
     bool solver_trace = false;   // GSC_SOLVER_TRACE: per-level clock stamps of the witness kernels
+    bool keep_secrets = false;   // GSC_KEEP_SECRETS: skip the end-of-call wipe of key wires / randomness in device memory (shows that the residue check sees them)
     bool few_test_abort = false; // GSC_FEW_TEST_ABORT: the resident witness kernel's barrier never fills (exercises the give-up path)
 };
 // Every knob is read HERE, once per InitAlgorithm / gsc_setup call — never on the proving path (getenv there would race with a
@@ -67,7 +71,8 @@ bool test_hooks_enabled();
 // Batch calls: the Z-table gather-accumulate k_msm_win<Fp29f>.  Calls on the latency path (a handful of statements): the resident
 // witness kernel k_solver_few, which is half of such a call.  statements = what the call proved; columns = the 64-padded batch the
 // kernels ran on; nbases = fixed bases per proof of the Z set.
-struct KernelStat { const char* name = ""; float ms = 0; size_t statements = 0, columns = 0, nbases = 0; float stage_ms[4] = {0, 0, 0, 0}; };
+// clock_mhz: the shader clock during the Z kernel (stamps of one wave in the middle of the launch), 0 when not measured; nwin: its digit windows.
+struct KernelStat { const char* name = ""; float ms = 0; size_t statements = 0, columns = 0, nbases = 0; float stage_ms[4] = {0, 0, 0, 0}; float clock_mhz = 0; int nwin = 0; };
 
 // what: 0 W (Montgomery), 1 A, 2 B, 3 C (Montgomery; valid until computeH overwrites them: only with keep_abc), 4 h (canonical, bit-reversed order)
 struct DebugVectors { std::vector<uint8_t> W, A, B, C, H; size_t n_wires = 0, n_constraints = 0, n = 0; };
@@ -80,12 +85,17 @@ class Algorithm {
     ~Algorithm();
     Cipher cipher() const;
     // proves n independent statements; results[i] corresponds to reqs[i].  Thread-safe (serialised per algorithm).
-    void prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first = nullptr);
+    // whole: the call is a batch the micro-batcher took for one device: it goes to ONE replica when it fits (dispatch.hpp plan_shares)
+    void prove_batch(const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first = nullptr, bool whole = false);
+    // forget the calling thread's "own last call" statistics (its next gsc_last_* query reports the chunk that finished last anywhere)
+    void forget_thread_stat() const;
     size_t max_batch() const;      // over all devices
     size_t devices() const;
     size_t lanes() const;          // lanes of one replica: how many device batches can be in flight per device
     std::string describe() const;    // sizes, table memory — for logs / DESIGN numbers
-    // timing of the chunk that finished last (any replica, any lane): stage milliseconds (solve, ntt, msm, finalize) and the dominant kernel
+    // Timing of the calling thread's own last prove_batch call (its chunk with the longest dominant kernel) — or, on a thread that has not
+    // called prove_batch itself (callers whose statements rode the micro-batcher), of the chunk that finished last on any replica, any lane:
+    // stage milliseconds (solve, ntt, msm, finalize) and the dominant kernel.
     KernelStat last_kernel_stat() const;
     // TEST HOOK: the quotient kernels alone on caller-supplied vectors.  abc_be: three matrices [m][64] of canonical big-endian
     // 32-byte values (a, then b, then c; 64 independent columns), m <= number of constraints.  h_out: [domain][64] 32-byte
@@ -95,6 +105,8 @@ class Algorithm {
     // d_out: [domain][64] little-endian canonical values, row i = A(zeta w^i) B(zeta w^i) * 2^261 mod r (natural order).
     void debug_compute_d(const uint8_t* ab_be, size_t m, uint8_t* d_out);
     size_t domain_size() const;
+    // TEST HOOK: bytes of secrets (key wires, r, s, input records, masks) still non-zero in device memory, all replicas and lanes; 0 after any call
+    size_t debug_secret_residue();
   private:
     std::vector<std::unique_ptr<AlgorithmImpl>> impls_;      // one per device
     std::unique_ptr<class ReplicaPicker> picker_;            // dispatch.hpp: least-loaded replica for calls that are not split

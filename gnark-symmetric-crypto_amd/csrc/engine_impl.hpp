@@ -118,6 +118,8 @@ class AlgorithmImpl {
         hipEvent_t ev_few = nullptr;    // completion of this lane's latest k_solver_few launch (FewSolverChain)
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
+        KernelStat stat;                // of the chunk this lane proved last
+        DevBuf<unsigned long long> d_clk;      // clock stamps of the Z kernel (MsmWinArgs::clk)
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
         size_t cap = 0;
         DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync; DevBuf<GlvSplit> d_glv;
@@ -230,6 +232,12 @@ class AlgorithmImpl {
     void flush_horner_g2(Lane& ln, size_t B, hipStream_t s) { launch_msm_horner_g2(ln.pending2, B, s); ln.pending2.n = 0; }
 
     void fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B, size_t col, std::vector<uint8_t>& out);
+    // The statement's secrets must not outlive the call in device memory (the witness of these circuits IS a cipher key): enqueued behind a
+    // chunk's last kernel, clears the key wires (32-byte rows and byte plane), the rows of r, s, -rs, the raw input records, the prover
+    // randomness, its endomorphism split and the commitment mask.  (The reference leaves all of this to Go's garbage collector.)
+    void wipe_secrets(Lane& ln, size_t B, bool small_call);
+    // TEST HOOK: non-zero bytes left in those areas over all lanes (after draining their streams)
+    size_t secret_residue();
 
     void prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver = true, bool allow_small = true);
 

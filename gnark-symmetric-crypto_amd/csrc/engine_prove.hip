@@ -98,7 +98,7 @@ void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set
         const size_t Bw = B * (size_t)set.nwin;
         MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ctx.digits};
         if (!digits_ready) launch_msm_recode(ra, ctx.stream);
-        MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa};
+        MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa, timed && !few ? ln.d_clk.p : nullptr};
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
         if (few) launch_win_few(a, n_real, ctx.stream);
         else launch_win(a, ctx.stream);
@@ -133,15 +133,52 @@ void AlgorithmImpl::fetch_column(Lane& ln, const fe* mat, size_t rows, size_t B,
     HIP_CHECK(hipStreamSynchronize(ln.stream));
 }
 
+void AlgorithmImpl::wipe_secrets(Lane& ln, size_t B, bool small_call) {
+    if (cfg.keep_secrets) return;      // (test hook: shows that secret_residue() sees what the wipe removes)
+    const size_t n_secret = n_inputs - n_public;
+    HIP_CHECK(hipMemsetAsync(ln.d_inputs.p, 0, 176 * B, ln.stream));
+    HIP_CHECK(hipMemsetAsync(ln.d_rs.p, 0, 64 * B, ln.stream));
+    HIP_CHECK(hipMemsetAsync(ln.d_glv.p, 0, ln.d_glv.bytes(), ln.stream));
+    if (has_commitment) { HIP_CHECK(hipMemsetAsync(ln.d_mask_in.p, 0, 32 * B, ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_mask.p, 0, B * sizeof(fe), ln.stream)); }
+    HIP_CHECK(hipMemsetAsync(ln.d_W.p + n_public * B, 0, n_secret * B * sizeof(fe), ln.stream));      // the key wires
+    HIP_CHECK(hipMemsetAsync(ln.d_W.p + n_wires * B, 0, 3 * B * sizeof(fe), ln.stream));               // r, s, -rs
+    if (small_call) HIP_CHECK(hipMemset2DAsync(ln.d_W8.p + n_public * 64, (size_t)small.rows_per_group * 64, 0, n_secret * 64, B / 64, ln.stream));
+}
+
+size_t AlgorithmImpl::secret_residue() {
+    HIP_CHECK(hipSetDevice(cfg.device));
+    size_t left = 0;
+    auto count = [&](const void* p, size_t bytes) {
+        std::vector<uint8_t> h(bytes);
+        HIP_CHECK(hipMemcpy(h.data(), p, bytes, hipMemcpyDeviceToHost));
+        for (uint8_t b : h) left += b != 0;
+    };
+    const size_t n_secret = n_inputs - n_public;
+    for (auto& lp : lanes) {
+        Lane& ln = *lp; const size_t B = ln.cap;
+        HIP_CHECK(hipStreamSynchronize(ln.stream));
+        count(ln.d_inputs.p, 176 * B); count(ln.d_rs.p, 64 * B); count(ln.d_glv.p, ln.d_glv.bytes());
+        if (has_commitment) { count(ln.d_mask_in.p, 32 * B); count(ln.d_mask.p, B * sizeof(fe)); }
+        // a chunk lays its rows out with ITS batch as the row stride (and wiped them in that layout): look where the lane's last chunk had them
+        const size_t Bl = ln.last_batch;
+        if (Bl) { count(ln.d_W.p + n_public * Bl, n_secret * Bl * sizeof(fe)); count(ln.d_W.p + n_wires * Bl, 3 * Bl * sizeof(fe)); }
+        if (small.ok) for (size_t g = 0; g < B / 64; g++) count(ln.d_W8.p + (g * small.rows_per_group + n_public) * 64, n_secret * 64);
+    }
+    return left;
+}
+
 void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* dbg, bool allow_few_solver, bool allow_small) {
     const size_t B = (n + 63) / 64 * 64;
     ln.n_real = n;
     const bool trace = cfg.trace_host;
     const auto tc0 = std::chrono::steady_clock::now();
-    std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs, n, B, h_in, h_rs);
+    struct Wiper { std::vector<uint8_t>& v; ~Wiper() { if (!v.empty()) explicit_bzero(v.data(), v.size()); } };      // host staging copies of key and randomness
+    std::vector<uint8_t> h_in, h_rs; Wiper wipe_in{h_in}, wipe_rs{h_rs};
+    pack_inputs(reqs, n, B, h_in, h_rs);
     ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
     ln.d_rs.upload(h_rs.data(), h_rs.size(), ln.stream);
     std::vector<GlvSplit> h_glv;                                     // (lives as long as the other staging vectors of the call)
+    struct GlvWiper { std::vector<GlvSplit>& v; ~GlvWiper() { if (!v.empty()) explicit_bzero(v.data(), v.size() * sizeof(GlvSplit)); } } wipe_glv{h_glv};
     if (n <= (size_t)cfg.few_max && cfg.few_path && B == 64) {      // latency path: the two halves of s and r for k_fin_scalarmul_few
         h_glv.resize(2 * n);
         for (size_t i = 0; i < n; i++) for (int role = 0; role < 2; role++) {
@@ -155,8 +192,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     // 1. witness
     if (cipher == CHACHA20) launch_assign_chacha(ln.d_inputs.p, ln.d_W.p, B, ln.stream);
     else launch_assign_aes(ln.d_inputs.p, cipher == AES_128 ? 16 : 32, ln.d_W.p, B, ln.stream);
+    std::vector<uint8_t> h_mask; Wiper wipe_mask{h_mask};
     if (has_commitment) {
-        std::vector<uint8_t> h_mask(32 * B);
+        h_mask.resize(32 * B);
         for (size_t i = 0; i < B; i++) memcpy(h_mask.data() + 32 * i, reqs[i < n ? i : n - 1].mask, 32);
         ln.d_mask_in.upload(h_mask.data(), h_mask.size(), ln.stream);
     }
@@ -344,6 +382,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     uint32_t h_fsync[2] = {0, 0}, h_wsflag = 0;
     if (few_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
     if (small_call) HIP_CHECK(hipMemcpyAsync(&h_wsflag, ln.d_wsflag.p, 4, hipMemcpyDeviceToHost, ln.stream));
+    wipe_secrets(ln, B, small_call);      // behind the last kernel of the chunk, inside the wait below
+    unsigned long long h_clk[4] = {0, 0, 0, 0};
+    if (!latency_call) HIP_CHECK(hipMemcpyAsync(h_clk, ln.d_clk.p, 32, hipMemcpyDeviceToHost, ln.stream));
     const auto tc1 = std::chrono::steady_clock::now();
     HIP_CHECK(hipStreamSynchronize(ln.stream));
     const auto tc2 = std::chrono::steady_clock::now();
@@ -362,10 +403,14 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
     (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
     {
+        KernelStat& st = ln.stat;
+        st.name = latency_call ? (few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
+        st.ms = ln.msm_z_kernel_ms; st.statements = n; st.columns = B; st.nbases = mZ.nwide; st.nwin = mZ.nwin;
+        for (int k = 0; k < 4; k++) st.stage_ms[k] = ln.stage_ms[k];
+        // shader clock of the Z launch: (shader-clock ticks) / (100 MHz ticks) of one wave's life in the middle of the grid
+        st.clock_mhz = (!latency_call && h_clk[2] > h_clk[0] && h_clk[3] > h_clk[1]) ? (float)(100.0 * (double)(h_clk[3] - h_clk[1]) / (double)(h_clk[2] - h_clk[0])) : 0.f;
         std::lock_guard<std::mutex> lk(stat_mu);
-        last_stat.name = latency_call ? (few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
-        last_stat.ms = ln.msm_z_kernel_ms; last_stat.statements = n; last_stat.columns = B; last_stat.nbases = mZ.nwide;
-        for (int k = 0; k < 4; k++) last_stat.stage_ms[k] = ln.stage_ms[k];
+        last_stat = st;
     }
     for (size_t i = 0; i < n; i++)
         serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts.data() + 64 * i : nullptr, has_commitment ? h_cpts.data() + 64 * B + 64 * i : nullptr, results[i]);

@@ -156,7 +156,7 @@ void AlgorithmImpl::calibrate() {
     uint64_t x = 0x9E3779B97F4A7C15ull;
     auto next = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
     for (auto& q : reqs) {
-        memset(&q, 0, sizeof q);
+        q = ProofRequest{};
         q.keylen = cipher == AES_128 ? 16 : 32;
         for (uint32_t i = 0; i < q.keylen; i++) q.key[i] = (uint8_t)next();
         for (auto& b : q.nonce) b = (uint8_t)next();
@@ -472,6 +472,7 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
+    ln.d_clk.alloc(4); HIP_CHECK(hipMemsetAsync(ln.d_clk.p, 0, 32, ln.stream));
     ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2); ln.d_glv.alloc(2 * MSM_FEW_PROOFS);
     ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc((domain_n + 1) * B);      // (+ one row that stays zero: the padding slots of mC)
     // calls with a handful of statements (k_solver_few) write their own columns only: the others must always hold field elements

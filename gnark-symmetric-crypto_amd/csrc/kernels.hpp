@@ -192,6 +192,9 @@ struct MsmWinArgs {
     const uint4* digits; size_t batch;
     size_t nslices, per;           // per: a multiple of 8
     void* partial;                 // G1Xyzz / G2Xyzz [nslices][nwin][batch]
+    // diagnostics (bench.py's VALU roofline): the workgroup in the middle of the grid stamps {100 MHz clock, shader clock} when it starts and
+    // when it ends -> clk[0..3]; their ratio is the shader clock the launch really ran at (the chip is power-limited).  nullptr: no stamps.
+    unsigned long long* clk = nullptr;
 };
 void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s);
 void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s);

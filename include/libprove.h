@@ -91,6 +91,9 @@ extern long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t *abc_be,
  * csrc/k_quot_bases.hip).  ab_be: a, then b, each [m][64] canonical big-endian values.  d_out: [domain][64] canonical little-endian
  * values, row i = A(zeta w^i) * B(zeta w^i) * 2^261 mod r in natural order (zeta: the primitive 2n-th root of unity, w = zeta^2 the
  * domain generator; A, B the interpolation polynomials of a, b).  Returns the domain size (also for d_out == NULL), -1 on error. */
+/* TEST HOOK: bytes of a finished call's secrets (key wires of the witness, r, s, -rs, the raw input records, commitment masks) that are still
+ * non-zero in the algorithm's device buffers — the engine clears them behind the last kernel of every call, so 0; -1 on error / hooks disabled. */
+extern long long gsc_debug_secret_residue(GoUint8 algorithmID);
 extern long long gsc_debug_compute_d(GoUint8 algorithmID, const uint8_t *ab_be, size_t m, uint8_t *d_out, size_t cap);
 /* TEST HOOK (host arithmetic only, no GPU): the GLV split the latency path feeds to its scalar multiplications
  * (csrc/glv.hpp).  k: canonical scalar < r, 32 bytes little-endian.  out: 20 bytes |k1|, 20 bytes |k2| (little-endian), 4 bytes
@@ -108,6 +111,11 @@ extern int gsc_last_stage_ms(GoUint8 algorithmID, float out[4]);
  * statements the call proved; *columns: the 64-padded batch the kernels ran on; *nbases: fixed bases per proof of the Z set.
  * Any out pointer may be NULL.  Returns 0, -1 when the algorithm is not initialised. */
 extern int gsc_last_dominant_kernel(GoUint8 algorithmID, char *name, size_t cap, float *ms, size_t *statements, size_t *columns, size_t *nbases);
+/* For the same batch: *clock_mhz = the shader clock the Z-table kernel ran at (clock stamps of one wave in the middle of the launch; 0 when
+ * the call took the latency path), *windows = the digit windows of its Z set.  bench.py prices the kernel's VALU-issue roofline with them.
+ * The three gsc_last_* functions report the calling thread's own last gsc_prove_raw / ProveBatch call of more than 32 statements; on a thread
+ * that made none, the chunk that finished last on any replica. */
+extern int gsc_last_kernel_clock(GoUint8 algorithmID, float *clock_mhz, int *windows);
 
 #ifdef __cplusplus
 }

@@ -17,13 +17,15 @@ using namespace gsc;
 struct StubNode {
     ReplicaPicker picker; BatchScheduler sched; std::mutex mu; std::condition_variable done; std::deque<int*> q; bool stop = false;
     std::vector<std::thread> workers; std::vector<std::atomic<int>> batches_on; std::vector<size_t> batch_sizes;      // batch_sizes: under mu
-    int fixed_us, per_statement_us;
+    int fixed_us, per_statement_us; size_t cap_; std::atomic<size_t> split_batches{0};
     StubNode(size_t replicas, size_t lanes, size_t cap, int linger_us = 300, int fixed = 1000, int per = 100)
-        : picker(replicas), sched(replicas, cap, linger_us), batches_on(replicas), fixed_us(fixed), per_statement_us(per) {
+        : picker(replicas), sched(replicas, cap, linger_us), batches_on(replicas), fixed_us(fixed), per_statement_us(per), cap_(cap) {
         for (size_t i = 0; i < replicas * lanes; i++) workers.emplace_back([this] { run(); });
     }
     ~StubNode() { { std::lock_guard<std::mutex> l(mu); stop = true; } sched.cv.notify_all(); for (auto& w : workers) w.join(); }
-    void prove_batch(size_t n) {            // Algorithm::prove_batch for a call that is not split
+    void prove_batch(size_t n) {            // Algorithm::prove_batch(..., whole = true): a batcher share goes to ONE replica
+        const auto shares = plan_shares(n, picker.size(), cap_, true);
+        if (shares.size() != 1 || !shares[0].pick) split_batches++;
         const size_t r = picker.acquire(n);
         batches_on[r]++;
         std::this_thread::sleep_for(std::chrono::microseconds(fixed_us + per_statement_us * (int)n));      // a device batch: a fixed cost plus a share per statement
@@ -65,6 +67,32 @@ int main() {
         p.acquire_on(2, 128); CHECK(p.acquire(1) != 2); p.release(2, 128);
         printf("picker ok\n");
     }
+    {   // how Algorithm::prove_batch spreads a call over 8 replicas (plan_shares): contiguous shares, whole 64-column batches but for the
+        // last one, every statement in exactly one share; calls of up to one batch — and batches the micro-batcher took for one device — stay whole
+        const size_t cap = 8192;
+        for (size_t n : {(size_t)1, (size_t)64, (size_t)65, (size_t)4 * 64 + 37, (size_t)8 * 8192, (size_t)8 * 8192 - 37, (size_t)8191, (size_t)513}) {
+            const auto sh = plan_shares(n, 8, cap, false);
+            CHECK(!sh.empty() && sh.size() <= 8);
+            if (n <= 64) { CHECK(sh.size() == 1 && sh[0].pick && sh[0].off == 0 && sh[0].n == n); continue; }
+            size_t at = 0;
+            for (size_t k = 0; k < sh.size(); k++) {
+                CHECK(!sh[k].pick && sh[k].replica == k && sh[k].off == at && sh[k].n > 0 && sh[k].n <= cap);
+                if (k + 1 < sh.size()) CHECK(sh[k].n % 64 == 0);
+                at += sh[k].n;
+            }
+            CHECK(at == n);
+            std::vector<int> written(n, 0);
+            for (auto& x : sh) for (size_t i = x.off; i < x.off + x.n; i++) written[i]++;
+            for (int w : written) CHECK(w == 1);
+        }
+        CHECK(plan_shares(65, 8, cap, false).size() == 2 && plan_shares(65, 8, cap, false)[1].n == 1);
+        CHECK(plan_shares(8 * 8192, 8, cap, false).size() == 8 && plan_shares(8 * 8192, 8, cap, false)[7].n == 8192);
+        CHECK(plan_shares(0, 8, cap, false).empty() && plan_shares(70000, 1, cap, false).size() == 1);
+        // a batch the micro-batcher took for ONE device is not split again (256 closed-loop callers on 2 GPUs: two batches of 128, not four of 64)
+        CHECK(plan_shares(128, 2, 1024, true).size() == 1 && plan_shares(128, 2, 1024, true)[0].pick);
+        CHECK(plan_shares(1024, 2, 1024, true).size() == 1 && plan_shares(1025, 2, 1024, true).size() == 2 && plan_shares(128, 2, 1024, false).size() == 2);
+        printf("shares ok\n");
+    }
     CHECK(batcher_take(0, 3, 64) == 0 && batcher_take(1, 1, 64) == 1 && batcher_take(64, 2, 1024) == 32 && batcher_take(63, 1, 1024) == 63 &&
           batcher_take(5000, 1, 1024) == 1024 && batcher_take(3, 8, 64) == 1 && batcher_take(7, 0, 64) == 7);
     printf("take ok\n");
@@ -76,6 +104,17 @@ int main() {
         const auto sv = node.picker.served();
         printf("two replicas: calls %llu/%llu statements %llu/%llu\n", (unsigned long long)sv[0].calls, (unsigned long long)sv[1].calls, (unsigned long long)sv[0].statements, (unsigned long long)sv[1].statements);
         CHECK(sv[0].statements + sv[1].statements == 64 && sv[0].calls > 0 && sv[1].calls > 0);
+        CHECK(node.split_batches.load() == 0);      // every share the scheduler took went to one replica
+    }
+    {   // 256 closed-loop callers on two replicas: batches of more than 64 callers still go whole to one replica each
+        StubNode node(2, 1, 1024, 300, 2000, 20);
+        std::vector<std::thread> callers;
+        for (int i = 0; i < 256; i++) callers.emplace_back([&] { for (int k = 0; k < 4; k++) node.submit(); });
+        for (auto& t : callers) t.join();
+        size_t big = 0; for (size_t b : node.batch_sizes) big += b > 64;
+        const auto sv = node.picker.served();
+        printf("256 callers on two replicas: %zu batches, %zu of them above 64 callers, calls %llu/%llu\n", node.batch_sizes.size(), big, (unsigned long long)sv[0].calls, (unsigned long long)sv[1].calls);
+        CHECK(node.split_batches.load() == 0 && big > 0 && sv[0].calls + sv[1].calls == node.batch_sizes.size());
     }
     {   // sustained load on 8 replicas x 2 lanes: every replica serves, the spread is even within a factor of three
         StubNode node(8, 2, 64);

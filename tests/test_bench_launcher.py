@@ -59,3 +59,20 @@ def test_in_library_mode_is_one_process_for_all_devices():
     assert p.returncode != 0 and b"--devices lists 1 devices" in p.stderr
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--in-library", "--stub-prover"], env=dict(_env(), RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"), capture_output=True, timeout=120)
     assert p.returncode != 0 and b"one process for all GPUs" in p.stderr
+
+
+def test_eight_ranks_and_eight_in_library_replicas():
+    # the driver's scaling run is N = 1, 2, 4, 8 on one node: the same two launch paths at N = 8 (stub prover, gloo; 8 rank processes of
+    # this script with one torch import each, so give it time).  Every rank's shard enters the aggregate exactly once.
+    env = dict(_env(), MASTER_PORT=str(29650 + os.getpid() % 200))
+    out = subprocess.check_output([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "64", "--stub-prover"], env=env, timeout=900, stderr=subprocess.DEVNULL).decode()
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["scaling"] == "weak" and line["config"]["batch_per_gpu"] == 64
+    assert "8 GPU(s), one process per GPU" in line["config"]["parallelism"]
+    assert abs(line["value"] - 8 * 2 * 64 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 0.01
+    out = subprocess.check_output([sys.executable, BENCH, "--gpus", "8", "--in-library", "--steps", "2", "--warmup", "1", "--batch", "64", "--stub-prover"], env=_env(), timeout=300, stderr=subprocess.DEVNULL).decode()
+    line = json.loads([l for l in out.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == 8 and "GSC_DEVICES=0,1,2,3,4,5,6,7" in line["config"]["parallelism"] and "one call of 512 statements per step" in line["config"]["parallelism"]
+    assert abs(line["value"] - 8 * 2 * 64 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 0.01

@@ -1,6 +1,6 @@
 """Builds profiles/rNN_msm_z_pmc.json (what bench.py replays as roofline.traffic) from three rocprofv3 --pmc passes of
 `bench.py --steps 1 --warmup 1 --no-cpu-baseline`: FETCH_SIZE, WRITE_SIZE, TCC_HIT/MISS/REQ/EA0_RDREQ.
-usage: make_msm_z_pmc.py <fetch.csv> <write.csv> <tcc.csv> <out.json> [window_z] [batch] [nbases]
+usage: make_msm_z_pmc.py <fetch.csv> <write.csv> <tcc.csv> <out.json> [window_z] [batch] [nbases] [quotient form as gsc_describe prints it, e.g. evaluation-form+digits]
 (nbases: 32767 for the coefficient-form quotient, 32768 for the evaluation form, whose batches also launch the same kernel template with narrow
 digits for the wide rows of c: only the Z launch — the wide-digit instantiation at c = 17 — is counted)"""
 import csv, json, math, sys
@@ -33,7 +33,9 @@ E = 1 << (c - 1); g = 384 * 64.0                       # entries per row; lanes 
 model = 1.0 - (E / g) * (1.0 - math.exp(-g / E))
 out = {
     "kernel": "k_msm_win<Fp29f> over the Z rows (one row of 2^%d multiples per base, window-parallel accumulators, one XCD per slice)" % (c - 1),
-    "config": {"kernel": "chacha20", "batch": batch, "window_z": c, "grid_waves": (nbases + 255) // 256 * nwin * (batch // 64)},
+    # bench.py replays this file only for a run whose engine description matches every key here (quotient: the text after "quotient=" in gsc_describe)
+    "config": {"kernel": "chacha20", "batch": batch, "window_z": c, "nbases": nbases, "quotient": sys.argv[8] if len(sys.argv) > 8 else "evaluation-form+digits" if nbases == 32768 else "coefficient-form",
+               "grid_waves": (nbases + 255) // 256 * nwin * (batch // 64)},
     "FETCH_SIZE_KB_per_launch": fetch["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": write["WRITE_SIZE"],
     "hbm_bytes_per_launch": int((fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024),
     "algorithmic_bytes_per_launch": batch * nbases * 96,
