@@ -20,7 +20,7 @@ CHACHA20, AES_128, AES_256 = 0, 1, 2                       # prove_impl.go:15-19
 ALGORITHM_NAMES = {0: "chacha20", 1: "aes-128-ctr", 2: "aes-256-ctr"}   # prove_impl.go:21-25
 
 EXPORTS = ["enforce_binding", "InitAlgorithm", "Free", "Prove", "ProveBatch", "gsc_prove_raw", "gsc_setup",
-           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_dominant_kernel", "gsc_last_kernel_clock", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_compute_d", "gsc_debug_secret_residue", "gsc_debug_glv_split"]
+           "gsc_set_deterministic_randomness", "gsc_debug_prove", "gsc_debug_vector", "gsc_describe", "gsc_last_stage_ms", "gsc_last_dominant_kernel", "gsc_last_kernel_clock", "gsc_debug_field_ops", "gsc_debug_compute_h", "gsc_debug_compute_d", "gsc_debug_secret_residue", "gsc_debug_clock_trace", "gsc_debug_glv_split"]
 
 
 class GoSlice(C.Structure):
@@ -210,6 +210,18 @@ def debug_secret_residue(algorithm_id: int) -> int:
     lib().gsc_debug_secret_residue.restype = C.c_longlong
     lib().gsc_debug_secret_residue.argtypes = [C.c_ubyte]
     return int(lib().gsc_debug_secret_residue(algorithm_id))
+
+
+def debug_clock_trace(n: int, interval_us: int):
+    """TEST HOOK: [(seconds since the first sample, shader clock in MHz over the interval before it)] from a resident one-wave sampler; blocks
+    for n x interval_us microseconds — run it in a thread beside the calls to be observed."""
+    buf = (C.c_ulonglong * (2 * n))()
+    lib().gsc_debug_clock_trace.restype = C.c_int
+    lib().gsc_debug_clock_trace.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong)]
+    if lib().gsc_debug_clock_trace(n, interval_us, buf) != 0:
+        raise RuntimeError("gsc_debug_clock_trace failed")
+    v = list(buf)
+    return [((v[2 * i] - v[0]) / 1e8, 100.0 * (v[2 * i + 1] - v[2 * i - 1]) / max(1, v[2 * i] - v[2 * i - 2])) for i in range(1, n)]
 
 
 def last_kernel_clock(algorithm_id: int):

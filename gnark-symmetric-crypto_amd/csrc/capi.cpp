@@ -445,6 +445,12 @@ int gsc_debug_field_ops(int field, int op, const uint8_t* a, const uint8_t* b, u
     catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
 }
 
+int gsc_debug_clock_trace(uint32_t n, uint32_t interval_us, unsigned long long* out) {
+    if (hooks_refused("gsc_debug_clock_trace") || !out || !n) return -1;
+    try { debug_clock_trace(config_from_env().device, n, interval_us, out); return 0; }
+    catch (const std::exception& e) { printf("%s\n", e.what()); return -1; }
+}
+
 int gsc_debug_glv_split(const uint8_t* k, uint8_t* out) {
     if (hooks_refused("gsc_debug_glv_split") || !k || !out) return -1;
     uint32_t w[8]; memcpy(w, k, 32);

@@ -67,6 +67,18 @@ void debug_field_ops(int device, int field, int op, const uint8_t* a, const uint
     HIP_CHECK(hipMemcpy(out, dout.p, 32 * n, hipMemcpyDeviceToHost));
 }
 
+void debug_clock_trace(int device, uint32_t n, uint32_t interval_us, unsigned long long* out) {
+    HIP_CHECK(hipSetDevice(device));
+    hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    DevBuf<unsigned long long> d(2 * (size_t)n);
+    launch_clock_trace(d.p, n, interval_us * 100u, st);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d.p, 16 * (size_t)n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    HIP_CHECK(e);
+}
+
 // ---- Algorithm: one replica of the engine per device (GSC_DEVICES), batches split over the replicas ----
 Algorithm::Algorithm(Cipher cipher, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cfg) {
     std::vector<int> devs = cfg.devices.empty() ? std::vector<int>{cfg.device} : cfg.devices;

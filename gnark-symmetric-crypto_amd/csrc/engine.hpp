@@ -113,6 +113,9 @@ class Algorithm {
     mutable std::atomic<size_t> last_replica_{0};            // the replica whose chunk finished last (last_kernel_stat)
 };
 
+// TEST HOOK: samples the device's shader clock for n x interval_us microseconds beside whatever else runs (a resident one-wave kernel on a
+// stream of its own); out: n pairs {100 MHz clock, shader clock}.  Blocks until the samples are in.
+void debug_clock_trace(int device, uint32_t n, uint32_t interval_us, unsigned long long* out);
 // TEST HOOK: runs element-wise operations of the device's radix-2^29 field implementation (see kernels.hpp launch_field_ops).
 // a, b, out: n x 32 bytes little-endian canonical values (host memory).  Throws on HIP errors / missing GPU.
 void debug_field_ops(int device, int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int chain);

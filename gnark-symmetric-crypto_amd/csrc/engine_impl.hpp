@@ -119,7 +119,7 @@ class AlgorithmImpl {
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
         KernelStat stat;                // of the chunk this lane proved last
-        DevBuf<unsigned long long> d_clk;      // clock stamps of the Z kernel (MsmWinArgs::clk)
+        DevBuf<unsigned long long> d_clk;      // clock stamps of the Z kernel (MsmWinArgs::clk); [4 ..16): of the three transform kernels (GSC_TRACE_HOST)
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
         size_t cap = 0;
         DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync; DevBuf<GlvSplit> d_glv;

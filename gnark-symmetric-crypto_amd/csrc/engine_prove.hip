@@ -316,7 +316,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     }
     // 2. quotient polynomial.  Coefficient form: h overwrites A, canonical, bit-reversed order (six transforms).  Evaluation form (batch calls,
     // k_quot_bases.hip): d = A B on the zeta-coset overwrites A, natural order (four transforms); c stays where the solver wrote it.
-    NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p};
+    NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, trace ? ln.d_clk.p + 4 : nullptr};
     const NttNarrow planes{{ln.d_A8.p, ln.d_B8.p, ln.d_C8.p}, n_constraints};
     const NttNarrow* narrow = small_call ? &planes : nullptr;      // a, b (and c) of this chunk are byte planes
     HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
@@ -383,8 +383,8 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     if (few_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
     if (small_call) HIP_CHECK(hipMemcpyAsync(&h_wsflag, ln.d_wsflag.p, 4, hipMemcpyDeviceToHost, ln.stream));
     wipe_secrets(ln, B, small_call);      // behind the last kernel of the chunk, inside the wait below
-    unsigned long long h_clk[4] = {0, 0, 0, 0};
-    if (!latency_call) HIP_CHECK(hipMemcpyAsync(h_clk, ln.d_clk.p, 32, hipMemcpyDeviceToHost, ln.stream));
+    unsigned long long h_clk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!latency_call) HIP_CHECK(hipMemcpyAsync(h_clk, ln.d_clk.p, trace ? 128 : 32, hipMemcpyDeviceToHost, ln.stream));
     const auto tc1 = std::chrono::steady_clock::now();
     HIP_CHECK(hipStreamSynchronize(ln.stream));
     const auto tc2 = std::chrono::steady_clock::now();
@@ -418,6 +418,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         const auto tc3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "prove_chunk(%zu): enqueue %.2f ms, wait %.2f ms, serialise %.2f ms\n", n, ms(tc0, tc1), ms(tc1, tc2), ms(tc2, tc3));
+        auto mhz = [&](int k) { const unsigned long long* c = h_clk + 4 * k; return c[2] > c[0] && c[3] > c[1] ? 100.0 * (double)(c[3] - c[1]) / (double)(c[2] - c[0]) : 0.0; };
+        if (!latency_call) fprintf(stderr, "prove_chunk(%zu): shader clock (one workgroup in the middle of each launch): transforms %.0f / %.0f / %.0f MHz, Z kernel %.0f MHz; stages %.2f / %.2f / %.2f / %.2f ms\n", n, mhz(1), mhz(2), mhz(3), mhz(0),
+                                   ln.stage_ms[0], ln.stage_ms[1], ln.stage_ms[2], ln.stage_ms[3]);
     }
 }
 

@@ -472,8 +472,10 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
-    ln.d_clk.alloc(4); HIP_CHECK(hipMemsetAsync(ln.d_clk.p, 0, 32, ln.stream));
+    ln.d_clk.alloc(16); HIP_CHECK(hipMemsetAsync(ln.d_clk.p, 0, 128, ln.stream));
     ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2); ln.d_glv.alloc(2 * MSM_FEW_PROOFS);
+    // (the buffers that will hold secrets start out clean, so that "nothing of a call is left" can be checked from the first call on)
+    HIP_CHECK(hipMemsetAsync(ln.d_inputs.p, 0, ln.d_inputs.bytes(), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_rs.p, 0, ln.d_rs.bytes(), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_glv.p, 0, ln.d_glv.bytes(), ln.stream));
     ln.d_W.alloc((n_wires + 4) * B); ln.d_A.alloc(domain_n * B); ln.d_B.alloc(domain_n * B); ln.d_C.alloc((domain_n + 1) * B);      // (+ one row that stays zero: the padding slots of mC)
     // calls with a handful of statements (k_solver_few) write their own columns only: the others must always hold field elements
     // (zero, later whatever an earlier call left there) because the transforms and MSMs run over whole 64-column batches
@@ -531,6 +533,9 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     for (int k = 0; k < Lane::NSETS; k++) { ln.d_sj1[k].alloc(sj1[k] ? sj1[k] : 1); ln.d_flat1[k].alloc(g1sets[k]->nflat && g1sets[k]->nwide ? B : 1); }
     ln.d_sj2.alloc(sj2 ? sj2 : 1); ln.d_flat2.alloc(B);
     ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumC.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
-    if (has_commitment) { ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B); }
+    if (has_commitment) {
+        ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B);
+        HIP_CHECK(hipMemsetAsync(ln.d_mask_in.p, 0, ln.d_mask_in.bytes(), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_mask.p, 0, ln.d_mask.bytes(), ln.stream));
+    }
 }
 }  // namespace gsc

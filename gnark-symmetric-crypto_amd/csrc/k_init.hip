@@ -265,6 +265,24 @@ void launch_field_ops(int field, int op, const fe* a, const fe* b, fe* out, size
 namespace {
 }  // namespace
 
+// Diagnostics: ONE wave that samples {100 MHz clock, shader clock} every `interval` ticks of the 100 MHz clock, `n` times.  Launched on a
+// stream of its own before a call, it stays resident beside the call's kernels and shows the shader clock each of them is granted.
+namespace {
+__global__ __launch_bounds__(64) void k_clock_trace(unsigned long long* out, uint32_t n, uint32_t interval) {
+    if (threadIdx.x) return;
+    unsigned long long next = wall_clock64();
+    for (uint32_t i = 0; i < n; i++) {
+        unsigned long long t;
+        while ((t = wall_clock64()) < next) __builtin_amdgcn_s_sleep(32);
+        out[2 * i] = t; out[2 * i + 1] = clock64();
+        next = t + interval;
+    }
+}
+}  // namespace
+void launch_clock_trace(unsigned long long* out, uint32_t n, uint32_t interval_100mhz_ticks, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_clock_trace, dim3(1), dim3(64), 0, s, out, n, interval_100mhz_ticks);
+}
+
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 void launch_decompress_g1(const uint8_t* in, G1Aff* out, uint8_t* status, size_t n, hipStream_t s) {

@@ -218,6 +218,14 @@ __device__ __forceinline__ fe9 narrow9(int t) {
     return r;
 }
 
+struct ClkStamp {      // diagnostics: the shader clock a kernel runs at = (shader-clock ticks) / (100 MHz ticks) over the life of one workgroup in the middle of the grid
+    unsigned long long* p;
+    __device__ __forceinline__ ClkStamp(unsigned long long* clk, int slot) : p(nullptr) {
+        if (clk && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0) { p = clk + 4 * slot; p[0] = wall_clock64(); p[1] = clock64(); }
+    }
+    __device__ __forceinline__ void end() const { if (p) { p[2] = wall_clock64(); p[3] = clock64(); } }
+};
+
 // K1: strided DIF head.  grid (2^Llo, batch/P, nvec); block (2^(Lhi-2) * P).  Input: the solver's a/b/c rows (canonical values of
 // the 2^256 Montgomery domain); they are used as they are — every stage is linear, and K2's scale table folds in the
 // change of domain (2^256 -> 2^261).
@@ -228,6 +236,7 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
     fe* vec = blockIdx.z == 0 ? v0 : blockIdx.z == 1 ? v1 : v2;
     const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
     const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
+    const ClkStamp cs(pl.clk, 0);
     Tile t{smem, G * P};
     const int8_t* plane = blockIdx.z == 0 ? nr.plane[0] : blockIdx.z == 1 ? nr.plane[1] : nr.plane[2];
     if (plane) {      // (wave-uniform) the small-integer witness path left this vector as a byte plane; the few wide rows are 32-byte elements in `vec`
@@ -253,6 +262,7 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
         const size_t idx = ((size_t)e << Llo) + g;
         store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
+    cs.end();
 }
 
 // K2: contiguous DIF tail, scale by zeta^j / n (and into the 2^261 domain), contiguous DIT head.  grid (2^Lhi, batch/P, 2: a, b); block (2^(Llo-2) * P)
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
     fe* vec = blockIdx.z == 0 ? v0 : blockIdx.z == 1 ? v1 : v2;
     const uint32_t b = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
     const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
+    const ClkStamp cs(pl.clk, 1);
     Tile t{smem, Cn * P};
     for (uint32_t e = u4; e < Cn; e += Cn / 4) {
         const size_t idx = ((size_t)b << Llo) + e;
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
         const size_t idx = ((size_t)b << Llo) + e;
         store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
+    cs.end();
 }
 
 // K3: strided DIT tail for a and b; d = a*b on the zeta-coset; strided DIF head for d (written over a).  The last DIT stage and the
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
     const uint32_t G = 1u << Lhi;
     const uint32_t g = blockIdx.x; const size_t q0 = (size_t)blockIdx.y * P;
     const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
+    const ClkStamp cs(pl.clk, 2);
     Tile t{smem, G * P};
     fe9 lo0, hi0, lo1, hi1;        // running values at elements (u4 + j*G/4) and (u4 + j*G/4 + G/2), j = 0, 1
     for (int k = 0; k < 2; k++) {
@@ -347,6 +360,7 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
             if (c > 16) qd.digits[2 * at + half] = make_uint4(w[0], w[1], w[2], w[3]);
             else reinterpret_cast<uint2*>(qd.digits + at)[half] = make_uint2((w[0] & 0xFFFFu) | (w[1] << 16), (w[2] & 0xFFFFu) | (w[3] << 16));
         }
+        cs.end();
         return;
     }
     auto first_dif = [&](uint32_t e1, const fe9& lo, const fe9& hi) {       // first DIF stage (s = 0) on d: same pairs; twiddle exponent = gidx(e1) mod n/2

@@ -35,6 +35,9 @@ void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* n_inv,
 // TEST HOOK: radix-2^29 field self-test.  field 0 = Fp, 1 = Fr; a, b, out: n canonical 32-byte little-endian values (device memory).
 void launch_field_ops(int field, int op, const fe* a, const fe* b, fe* out, size_t n, int chain, hipStream_t s);
 
+// TEST HOOK / diagnostics: one resident wave records n samples {100 MHz clock, shader clock} `interval` 100 MHz ticks apart into out[2 n]
+void launch_clock_trace(unsigned long long* out, uint32_t n, uint32_t interval_100mhz_ticks, hipStream_t s);
+
 // ---- witness generation (k_solver.hip) ----
 // inputs: batch x 176 B records {key[32], nonce[12], counter u32 LE, pt[64], ct[64]} (ChaCha) laid out per proof.
 // W layout: W[wire * batch + proof].
@@ -115,7 +118,8 @@ void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint
 // an entry 0, 1, -1 stands for that value (its 2^256 Montgomery image), WS_PLANE_WIDE says the row's 32-byte element is in the vector itself.
 constexpr int8_t WS_PLANE_WIDE = -128;
 struct NttNarrow { const int8_t* plane[3]; size_t crows; };      // plane[(group * crows + row) * 64 + lane]
-struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* half_c; const int32_t* qr; };   // tw_*, qr: 12 int32 per entry (limbs)
+struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* half_c; const int32_t* qr;
+                 unsigned long long* clk = nullptr; };      // clk (diagnostics): kernel k's middle workgroup stamps {100 MHz clock, shader clock} at its start and end into clk[4 k ..]   // tw_*, qr: 12 int32 per entry (limbs)
 constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_QMAX .. NTT_QMAX (range reduction by the top limb)
 // a,b,c: [n][batch] Montgomery, first m rows valid (rows >= m are treated as zero and need not be initialised), c = a*b row by row
 // (a satisfied constraint system; otherwise the result is not gnark's).  On return `a` holds h in canonical form:

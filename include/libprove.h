@@ -91,6 +91,9 @@ extern long long gsc_debug_compute_h(GoUint8 algorithmID, const uint8_t *abc_be,
  * csrc/k_quot_bases.hip).  ab_be: a, then b, each [m][64] canonical big-endian values.  d_out: [domain][64] canonical little-endian
  * values, row i = A(zeta w^i) * B(zeta w^i) * 2^261 mod r in natural order (zeta: the primitive 2n-th root of unity, w = zeta^2 the
  * domain generator; A, B the interpolation polynomials of a, b).  Returns the domain size (also for d_out == NULL), -1 on error. */
+/* TEST HOOK: n samples {100 MHz clock, shader clock}, interval_us apart, taken by a one-wave kernel that stays resident beside whatever the
+ * device runs meanwhile (call it from a thread of its own around a Prove): the shader clock each kernel of a call is granted.  Blocks. */
+extern int gsc_debug_clock_trace(uint32_t n, uint32_t interval_us, unsigned long long *out);
 /* TEST HOOK: bytes of a finished call's secrets (key wires of the witness, r, s, -rs, the raw input records, commitment masks) that are still
  * non-zero in the algorithm's device buffers — the engine clears them behind the last kernel of every call, so 0; -1 on error / hooks disabled. */
 extern long long gsc_debug_secret_residue(GoUint8 algorithmID);

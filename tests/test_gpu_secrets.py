@@ -34,7 +34,7 @@ for n in (1, 5, 64, 200):                     # latency path, its multi-statemen
     left.append(g.debug_secret_residue(algo))
 r = recs[:112]
 out = g.prove({"cipher": cipher, "key": list(r[:kl]), "nonce": list(r[32:44]), "counter": int.from_bytes(r[44:48], "little"), "input": list(r[48:112])})
-assert "proofJson" in out
+assert b"proofJson" in (out if isinstance(out, bytes) else out.encode())
 left.append(g.debug_secret_residue(algo))
 print("RESIDUE", left)
 print("CHILD-OK")
