@@ -362,12 +362,12 @@ def roofline_of(n, rows, g):
     latency path (a handful of statements) -> the resident witness kernel priced on §8(d)'s witness bytes.  Bytes are counted for the
     STATEMENTS the launch proved, not for the 64-column padding."""
     kname = rows[-1][0]; avg_ms = sum(r[1] for r in rows) / len(rows); stmts, cols, nb = rows[-1][2], rows[-1][3], rows[-1][4]
-    solver = kname.startswith("k_solver")
+    solver = kname.startswith("k_solver") or kname.startswith("k_wit_")      # calls on the latency path: the witness kernels are the dominant ones
     alg_bytes = stmts * (WITNESS_BYTES_PER_PROOF[n] if solver else nb * MSM_Z_BYTES_PER_BASE)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     msm_ms = sum(r[5]["msm"] for r in rows) / len(rows)
     traffic, src = (None, None) if solver else pmc_traffic(n, cols, g.describe(ALGOS[n][0]))
-    return {"kernel": "%s (%s, %s)" % (kname, "resident witness solver of the latency path" if solver else "Z-table gather-accumulate", n), "bound": "hbm",
+    return {"kernel": "%s (%s, %s)" % (kname, "witness solver of the latency path" if solver else "Z-table gather-accumulate", n), "bound": "hbm",
             "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic, "traffic_source": src, "launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
             "proofs_per_launch": stmts, "columns_per_launch": cols,
@@ -612,7 +612,7 @@ def main():
             roofs = {n: roofline_of(n, rows, g) for n, rows in per.items()}
             dom = max(roofs, key=lambda n: roofs[n]["launch_ms"])
             line["roofline"] = dict(roofs[dom])
-            if not roofs[dom]["kernel"].startswith("k_solver"):
+            if roofs[dom]["kernel"].startswith("k_msm_win"):
                 rv = roofline_valu_of(roofs[dom], per[dom], 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count)
                 if rv:
                     line["roofline_valu"] = rv

@@ -202,7 +202,7 @@ class AlgorithmImpl {
         n = (nbases + per - 1) / per;
         return n ? n : 1;
     }
-    static constexpr size_t WIN_SLICE = 256;      // bases per slice of the windowed kernel at full batches (measured 64 .. 512: kernel time within 1 %)
+    size_t WIN_SLICE = 256;      // bases per slice of the windowed kernel at full batches (measured 64 .. 512: kernel time within 1 %)
     bool few_solver_wanted(size_t n, size_t B) const { return n <= (size_t)cfg.few_max && B == 64 && cfg.few_solver; }
     struct MsmCtx { hipStream_t stream; uint4* digits; uint8_t* gok; const int8_t* plane = nullptr; size_t plane_rows = 0, plane_stride = 0; };      // plane: the scalars' byte plane (small-integer witness path)
     // the byte plane that stands for the scalar matrix `scalars` in the chunk this lane is proving (none: the matrix holds every row)

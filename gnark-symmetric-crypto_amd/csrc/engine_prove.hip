@@ -209,7 +209,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         if (!few_solver_wanted(n, B)) for (uint32_t l = 0; l < n_levels; l++) init[16 * l] = ~0ull;
         d_trace.alloc(init.size()); HIP_CHECK(hipMemcpy(d_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice)); sa.trace = d_trace.p;
     }
-    bool few_solver = few_solver_wanted(n, B) && allow_few_solver;
+    const bool latency_call0 = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;
+    const bool small_call0 = small.ok && allow_small && !strace && (!latency_call0 || cfg.small_witness_few);
+    bool few_solver = few_solver_wanted(n, B) && allow_few_solver && !small_call0;      // (the small-integer witness path needs no resident grid)
     if (few_solver) {      // a recent give-up on this replica: skip the resident kernel for a while (see few_skip)
         uint32_t k = few_skip.load();
         while (k && !few_skip.compare_exchange_weak(k, k - 1)) {}
@@ -217,7 +219,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     }
     const bool latency_call = n <= (size_t)cfg.few_max && cfg.few_path && B == 64;      // the call takes the latency kernels
     // Circuits whose witness is small integers (ChaCha20-V3): the integer kernels on byte planes (wit_small.hpp) instead of the level launches
-    const bool small_call = small.ok && allow_small && !latency_call && !strace;
+    const bool small_call = small_call0;
     ln.small_active = small_call;
     if (few_solver) HIP_CHECK(hipMemsetAsync(ln.d_fsync.p + 1, 0, 4, ln.stream));      // set by a resident launch that gave up at a barrier
     SolverFewArgs fa{few_ops.p, few_terms.p, few_lstart.p, 0, 0, coeff.p, coeff_inv.p, lookup_coeff.p, ln.d_W.p, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, (uint32_t)n,
@@ -404,7 +406,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
     {
         KernelStat& st = ln.stat;
-        st.name = latency_call ? (few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
+        st.name = latency_call ? (small_call ? "k_wit_chain + k_wit_rows" : few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
         st.ms = ln.msm_z_kernel_ms; st.statements = n; st.columns = B; st.nbases = mZ.nwide; st.nwin = mZ.nwin;
         for (int k = 0; k < 4; k++) st.stage_ms[k] = ln.stage_ms[k];
         // shader clock of the Z launch: (shader-clock ticks) / (100 MHz ticks) of one wave's life in the middle of the grid

@@ -23,6 +23,7 @@ const uint32_t kSmallCoeffs[5][8] = {
 AlgorithmImpl::AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf) : cipher(c), cfg(cf) {
     // measured crossover with the batch kernels (one 64-column batch: 12.9 ms ChaCha20, 43.7 ms AES): 32 statements for ChaCha20 (10.2 ms), ~23 for AES (8.2 ms + 1.6 ms each: 38.4 ms for 20)
     if (!cfg.few_max) cfg.few_max = cipher == CHACHA20 ? 32 : 20;
+    WIN_SLICE = (size_t)cfg.win_slice;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the GPU prover has no CPU fallback");
     HIP_CHECK(hipSetDevice(cfg.device));

@@ -218,5 +218,5 @@ def test_bench_bookkeeping_of_a_single_statement_call():
     # bytes are counted for the STATEMENTS a launch proved and for the kernel that was timed.  One statement per call:
     # the resident witness kernel of the latency path, SURVEY 8(d)'s witness bytes of ONE proof (not of 64 padded columns).
     one = _bench_line("--steps", "6", "--warmup", "2", "--batch", "1", "--callers", "1", "--verify", "1")["roofline"]      # one caller: concurrent small calls would share a launch
-    assert one["kernel"].startswith("k_solver_few") and one["proofs_per_launch"] == 1 and one["columns_per_launch"] == 64
+    assert one["kernel"].startswith("k_wit_chain") and one["proofs_per_launch"] == 1 and one["columns_per_launch"] == 64      # ChaCha20-V3: the small-integer witness kernels
     assert one["algorithmic_bytes_per_launch"] == 3012224 and one["traffic"] is None
