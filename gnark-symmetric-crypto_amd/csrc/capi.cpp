@@ -48,7 +48,7 @@ class Batcher {
     ~Batcher() { { std::lock_guard<std::mutex> l(mu_); stop_ = true; } sched_.cv.notify_all(); for (auto& w : workers_) if (w.joinable()) w.join(); }
     // blocks until the proof is done; throws std::runtime_error if the device batch failed
     void submit(const ProofRequest& req, ProofResult& out) {
-        Item it{&req, &out, false, std::string()};
+        Item it{&req, &out, false, std::string(), &it};
         { std::unique_lock<std::mutex> l(mu_); q_.push_back(&it); sched_.arrived(); done_cv_.wait(l, [&] { return it.done; }); }
         if (!it.error.empty()) throw std::runtime_error(it.error);
     }
@@ -59,14 +59,14 @@ class Batcher {
         std::vector<Item> items(n);
         {
             std::unique_lock<std::mutex> l(mu_);
-            for (size_t i = 0; i < n; i++) { items[i] = Item{&reqs[i], &out[i], false, std::string()}; q_.push_back(&items[i]); }
+            for (size_t i = 0; i < n; i++) { items[i] = Item{&reqs[i], &out[i], false, std::string(), items.data()}; q_.push_back(&items[i]); }
             sched_.arrived(n);
             done_cv_.wait(l, [&] { for (const Item& it : items) if (!it.done) return false; return true; });
         }
         for (const Item& it : items) if (!it.error.empty()) throw std::runtime_error(it.error);
     }
   private:
-    struct Item { const ProofRequest* req; ProofResult* res; bool done; std::string error; };
+    struct Item { const ProofRequest* req; ProofResult* res; bool done; std::string error; const void* call; };      // call: the same for all statements of one submit_many
     static int linger_from_env() { const char* e = getenv("GSC_LINGER_US"); return e && *e ? atoi(e) : 300; }
     void run() {
         for (;;) {
@@ -90,7 +90,9 @@ class Batcher {
             {
                 std::lock_guard<std::mutex> l(mu_);
                 for (size_t i = 0; i < take.size(); i++) { if (err.empty() && i < res.size()) *take[i]->res = res[i]; take[i]->error = err; take[i]->done = true; }
-                sched_.completed(take.size());
+                size_t calls = 0; const void* prev = nullptr;      // (the statements of a call are queued back to back)
+                for (Item* it : take) { if (it->call != prev) calls++; prev = it->call; }
+                sched_.completed(take.size(), calls);
             }
             done_cv_.notify_all();
         }

@@ -94,8 +94,9 @@ class BatchScheduler {
     BatchScheduler(size_t devices, size_t max_batch, int linger_us) : devices_(devices ? devices : 1), max_batch_(max_batch ? max_batch : 1), linger_us_(linger_us < 0 ? 0 : linger_us) {}
     std::condition_variable cv;             // workers wait here; notified on every arrival, completion and stop
     // caller side, lock held, after the item was queued
+    // (n statements of ONE call: a ProveBatch / gsc_prove_raw call of several statements comes back as one caller, not as n)
     void arrived(size_t n = 1) {
-        events_++; arrivals_since_done_ += n;
+        events_++; arrivals_since_done_ += 1;
         const Clock::time_point now = Clock::now();
         for (size_t i = 0; i < n; i++) queued_at_.push_back(now);
         if (now < return_hard_) { return_soft_ = now + std::chrono::microseconds(gap_us()); if (return_soft_ > return_hard_) return_soft_ = return_hard_; }
@@ -141,9 +142,12 @@ class BatchScheduler {
         in_flight_++; last_started_ = n;
         for (size_t i = 0; i < n && !queued_at_.empty(); i++) queued_at_.pop_front();
     }
-    void completed(size_t n) {                                                 // lock held, before the callers are woken
+    // lock held, before the callers are woken.  n statements of `calls` distinct calls (0: every statement its own caller): the callers that can
+    // come back are the CALLS — waiting for as many arrivals as the batch had statements would hold an idle device (up to the gap, re-armed by
+    // every arrival) whenever a call of several statements is followed by lone single-statement callers.
+    void completed(size_t n, size_t calls = 0) {
         if (in_flight_) in_flight_--;
-        events_++; returning_ = n; arrivals_since_done_ = 0;
+        events_++; returning_ = calls ? calls : n; arrivals_since_done_ = 0;
         const Clock::time_point now = Clock::now();
         return_soft_ = now + std::chrono::microseconds(gap_us()); return_hard_ = now + std::chrono::microseconds(linger_us_ ? RETURN_MAX_US : 0);
         if (return_soft_ > return_hard_) return_soft_ = return_hard_;

@@ -7,6 +7,8 @@
 #include <condition_variable>
 #include <cstdio>
 #include <deque>
+#include <map>
+#include <set>
 #include <thread>
 
 using namespace gsc;
@@ -42,11 +44,26 @@ struct StubNode {
                 sched.started(take.size()); batch_sizes.push_back(take.size());
             }
             prove_batch(take.size());
-            { std::lock_guard<std::mutex> l(mu); for (int* d : take) *d = 1; sched.completed(take.size()); }
+            {
+                std::lock_guard<std::mutex> l(mu);
+                std::set<size_t> calls;           // distinct calls in the batch (capi.cpp Batcher::run counts them the same way)
+                for (int* d : take) calls.insert(call_of[d]);
+                for (int* d : take) { call_of.erase(d); *d = 1; }
+                sched.completed(take.size(), calls.size());
+            }
             done.notify_all();
         }
     }
-    void submit() { int flag = 0; std::unique_lock<std::mutex> l(mu); q.push_back(&flag); sched.arrived(); done.wait(l, [&] { return flag != 0; }); }
+    void submit() { int flag = 0; std::unique_lock<std::mutex> l(mu); q.push_back(&flag); call_of[&flag] = next_call++; sched.arrived(); done.wait(l, [&] { return flag != 0; }); }
+    // Batcher::submit_many: n statements of ONE call
+    void submit_many(size_t n) {
+        std::vector<int> flags(n, 0); std::unique_lock<std::mutex> l(mu);
+        const size_t id = next_call++;
+        for (auto& f : flags) { q.push_back(&f); call_of[&f] = id; }
+        sched.arrived(n);
+        done.wait(l, [&] { for (int f : flags) if (!f) return false; return true; });
+    }
+    std::map<int*, size_t> call_of; size_t next_call = 0;      // the call every queued statement belongs to (under mu)
 };
 
 int main() {
@@ -126,6 +143,17 @@ int main() {
         for (auto& c : sv) { lo = c.statements < lo ? c.statements : lo; hi = c.statements > hi ? c.statements : hi; total += c.statements; }
         printf("eight replicas: statements min %llu max %llu total %llu\n", (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)total);
         CHECK(total == 48 * 20 && lo > 0 && hi <= 3 * lo + 8);
+    }
+    {   // a call of 32 statements followed by lone single-statement callers (a host that alternates ProveBatch with Prove): the 32 statements come
+        // back as ONE caller, so a lone Prove that arrives after them is not held on the idle device waiting for 31 more arrivals
+        StubNode node(1, 3, 1024, 300, 500, 10);
+        node.submit_many(32);
+        const uint64_t waits0 = node.sched.timed_waits();
+        for (int k = 0; k < 5; k++) { node.submit(); node.submit_many(32); }
+        printf("mixed small calls and single callers: %llu timed waits on an idle device\n", (unsigned long long)(node.sched.timed_waits() - waits0));
+        CHECK(node.sched.timed_waits() == waits0);
+        size_t total = 0; for (size_t b : node.batch_sizes) total += b;
+        CHECK(total == 32 + 5 * 33);
     }
     {   // closed loop on ONE device (libraries/core_test.go:44-111: every caller issues its next Prove when the previous one has returned):
         // after the first round the callers of a completed batch are waited for and ride ONE batch again — not several small ones

@@ -309,7 +309,8 @@ def test_resident_solver_gives_up_cleanly_and_the_call_is_solved_again():
     # one line on stderr.
     import subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_FEW_Z_GB="0", TEST_STATEMENTS="3")
+    # (GSC_SMALL_WITNESS_FEW=0: ChaCha20-V3's latency calls otherwise take the small-integer witness kernels and never launch the resident one)
+    env = dict(os.environ, GSC_MAX_BATCH="256", GSC_WINDOW_Z="6", GSC_W_TABLE_GB="8", GSC_FEW_Z_GB="0", TEST_STATEMENTS="3", GSC_SMALL_WITNESS_FEW="0")
     want = _digest({"TEST_STATEMENTS": "3"})
     out = subprocess.run([sys.executable, "-c", _OPTIONS_SCRIPT, ROOT, "0"], env=dict(env, GSC_FEW_TEST_ABORT="1"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
