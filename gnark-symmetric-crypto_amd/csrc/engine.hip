@@ -29,18 +29,20 @@ EngineConfig config_from_env() {
     c.lanes = env_int("GSC_LANES", 0);
     c.small_lanes = env_int("GSC_SMALL_LANES", -1);
     if (c.small_lanes > 8) throw std::runtime_error("GSC_SMALL_LANES must be at most 8");
-    c.min_split = (size_t)env_int("GSC_MIN_SPLIT", 256);
+    // test-only knobs (no product setting, no profile uses a non-default value): honoured with the load-time test-hooks flag only
+    const bool hooks = test_hooks_enabled();
+    c.min_split = (size_t)(hooks ? env_int("GSC_MIN_SPLIT", 256) : 256);
     c.bit_groups = env_int("GSC_BIT_GROUPS", 1);
     c.window_z = env_int("GSC_WINDOW_Z", 0);
     c.window_w = env_int("GSC_WINDOW_W", 0);
     c.z_table_gb = env_int("GSC_Z_TABLE_GB", 48);
     c.w_table_gb = env_int("GSC_W_TABLE_GB", 16);
-    c.row_margin_bits = env_int("GSC_ROW_MARGIN_BITS", 1);
+    c.row_margin_bits = hooks ? env_int("GSC_ROW_MARGIN_BITS", 1) : 1;
     c.few_path = env_int("GSC_FEW_PATH", 1);
     c.few_solver = env_int("GSC_FEW_SOLVER", 1);
     c.few_max = env_int("GSC_FEW_MAX", 0);
     if (c.few_max < 0 || c.few_max > (int)MSM_FEW_PROOFS) throw std::runtime_error("GSC_FEW_MAX must be in [0, 32]");
-    c.few_workgroups = env_int("GSC_FEW_WGS", 0);
+    c.few_workgroups = hooks ? env_int("GSC_FEW_WGS", 0) : 0;
     c.few_z_gb = env_int("GSC_FEW_Z_GB", 12);
     c.few_wide = env_int("GSC_FEW_WIDE", 1);
     c.quotient_eval = env_int("GSC_QUOTIENT_EVAL", 1);

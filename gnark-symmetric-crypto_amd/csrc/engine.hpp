@@ -37,16 +37,16 @@ struct EngineConfig {
     size_t max_batch = 1024;     // GSC_MAX_BATCH: proofs per device batch = capacity of every lane (rounded to a multiple of 64)
     int lanes = 0;               // GSC_LANES: concurrent HIP streams, each with batch buffers of its own, handed to concurrent calls / chunks; 0 = 1 for ChaCha20-V3, 2 for AES-V2
     int small_lanes = -1;        // GSC_SMALL_LANES: extra lanes of 512 proofs for calls that fit them (several small calls in flight at once); -1 = 2 for ChaCha20-V3, 0 for AES-V2
-    size_t min_split = 256;      // a call with at least 2*min_split proofs is spread over the lanes (GSC_MIN_SPLIT)
+    size_t min_split = 256;      // a call with at least 2*min_split proofs is spread over the lanes (GSC_MIN_SPLIT: test hooks only)
     int window_z = 0;            // digit width of the Z (quotient) rows: 2^(c-1) multiples of each of the n-1 bases; 0 = largest <= 16 that fits z_table_gb
     int window_w = 0;            // digit width of the A / B1 / B2 / K / commitment sets; 0 = largest <= 16 that fits w_table_gb
     int z_table_gb = 48, w_table_gb = 16;   // per-algorithm HBM budgets used when the widths are not given (all three algorithms of the reference fit one 288 GB device)
     int bit_groups = 1;          // GSC_BIT_GROUPS: 0 no prediction-based layout; 1 bit groups / row lengths from a calibration witness; 2 every wire predicted a bit (test: exercises the fallbacks)
-    int row_margin_bits = 1;     // GSC_ROW_MARGIN_BITS: a wire seen with k-bit values gets a row of 2^(k + margin) multiples (capped at 2^(c-1))
+    int row_margin_bits = 1;     // GSC_ROW_MARGIN_BITS (test hooks only): a wire seen with k-bit values gets a row of 2^(k + margin) multiples (capped at 2^(c-1))
     int few_path = 1;            // GSC_FEW_PATH: calls with at most few_max statements use the latency kernels for the MSMs, the quotient and the assembly; 0 = always the batch kernels
     int few_max = 0;             // GSC_FEW_MAX: the largest call the latency kernels take (<= MSM_FEW_PROOFS = 32); 0 = 32 for ChaCha20 (4.6 ms for 1 statement, 7.8 ms for 16, 11.3 ms for 32; the batch kernels need 12.3 ms for anything up to 64), 20 for AES (8.2 ms for 1, +1.6 ms each: 38.4 ms for 20; batch kernels 43.7 ms)
     int few_solver = 1;          // GSC_FEW_SOLVER: such calls also solve the witness with the resident lanes-are-terms kernel (k_solver_few); 0 = one launch per level
-    int few_workgroups = 0;      // GSC_FEW_WGS: its grid (workgroups of 8 waves, one per CU, so all are resident); 0 = 128 for 1-2 statements, 256 beyond
+    int few_workgroups = 0;      // GSC_FEW_WGS (test hooks only): its grid (workgroups of 8 waves, one per CU, so all are resident); 0 = 128 for 1-2 statements, 256 beyond
     int few_z_gb = 12;           // GSC_FEW_Z_GB: HBM budget of the latency-path layout of the quotient bases (rows per (base, window) of 8-, 6- or 4-bit digits: 8.6 GB ChaCha20 at 8, 11.5 GB AES at 6); 0 = none, such calls run the Horner pass
     int few_wide = 1;            // GSC_FEW_WIDE: the wide wires of the wire sets (AES: ~6 k per set) also get (base, window) rows for the latency path (~7.5 GB per AES algorithm); 0 = such calls run the windowed kernel + Horner for them
     int quotient_eval = 1;       // GSC_QUOTIENT_EVAL: batch calls take the quotient in evaluation form (k_quot_bases.hip: four transforms instead of six, the Z sum over the

@@ -45,7 +45,47 @@ template <int K> __device__ __forceinline__ void chain_item(const Bundle& b, con
     Wg[(size_t)bfield<K, 1>(b) * 64 + lane] = (int8_t)w;               // (padding items write 0 to the scratch row)
 }
 
+// the terms of one part of an nBits sum: lane t < 32 holds term t
+struct PartTerms { uint32_t tw; long long tc; };
+__device__ __forceinline__ PartTerms part_fetch(const uint32_t* __restrict__ twire, const long long* __restrict__ tcoef, uint32_t tt, uint32_t lane) { return PartTerms{twire[tt + (lane & 31)], tcoef[tt + (lane & 31)]}; }
+struct PartVals { int v[WS_PART_CHUNKS * WS_CHUNK]; };
+__device__ __forceinline__ PartVals part_load(const PartTerms& t, uint32_t nch, const int8_t* __restrict__ Wg, uint32_t lane) {
+    PartVals r;
+#pragma unroll
+    for (uint32_t c = 0; c < WS_PART_CHUNKS; c++) {
+        if (c < nch) {
+#pragma unroll
+            for (uint32_t k = 0; k < WS_CHUNK; k++) r.v[c * WS_CHUNK + k] = (int)Wg[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)t.tw, c * WS_CHUNK + k) * 64 + lane];
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < WS_CHUNK; k++) r.v[c * WS_CHUNK + k] = 0;
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ long long part_sum(const PartTerms& t, const PartVals& pv, uint32_t nch) {
+    const int clo = (int)(uint32_t)t.tc, chi = (int)(t.tc >> 32);
+    long long acc = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < WS_PART_CHUNKS * WS_CHUNK; k++) {      // (terms beyond the part: coefficient 0 or value 0)
+        const long long cf = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(chi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(clo, k));
+        acc += (k < nch * WS_CHUNK ? cf : 0) * (long long)pv.v[k];
+    }
+    return acc;
+}
+struct BundleVals { TinyVals v0, v1, v2, v3, v4, v5, v6, v7; };
+__device__ __forceinline__ BundleVals bundle_load(const Bundle& b, const int8_t* __restrict__ Wg, uint32_t lane) {
+    return BundleVals{tiny_load<0>(b, Wg, lane), tiny_load<1>(b, Wg, lane), tiny_load<2>(b, Wg, lane), tiny_load<3>(b, Wg, lane), tiny_load<4>(b, Wg, lane), tiny_load<5>(b, Wg, lane), tiny_load<6>(b, Wg, lane), tiny_load<7>(b, Wg, lane)};
+}
+__device__ __forceinline__ void bundle_finish(const Bundle& b, const BundleVals& v, int8_t* __restrict__ Wg, uint32_t lane, bool& bad) {
+    chain_item<0>(b, v.v0, Wg, lane, bad); chain_item<1>(b, v.v1, Wg, lane, bad); chain_item<2>(b, v.v2, Wg, lane, bad); chain_item<3>(b, v.v3, Wg, lane, bad);
+    chain_item<4>(b, v.v4, Wg, lane, bad); chain_item<5>(b, v.v5, Wg, lane, bad); chain_item<6>(b, v.v6, Wg, lane, bad); chain_item<7>(b, v.v7, Wg, lane, bad);
+}
+
 // One workgroup per group of 64 proofs walks every level that produces wires; NW waves share a level's items.
+// A level costs its dependent memory round trips: wire loads, then the stores' acknowledgement before the barrier.  The descriptors of a
+// wave's FIRST bundle and part of the next level (static data) are therefore fetched while the current level computes — for ChaCha20-V3 a
+// wave never has more than one of each per level — so that nothing but the wire loads stands between a barrier and the arithmetic.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_wit_chain(const uint32_t* __restrict__ tiny, const uint32_t* __restrict__ parts, const uint32_t* __restrict__ bits, const uint32_t* __restrict__ twire,
                                                        const long long* __restrict__ tcoef, const uint32_t* __restrict__ levels, uint32_t nlevels, int8_t* __restrict__ W8, size_t rows_per_group, uint32_t* __restrict__ flag) {
@@ -53,42 +93,51 @@ __global__ __launch_bounds__(64 * NW) void k_wit_chain(const uint32_t* __restric
     const uint32_t lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
     int8_t* __restrict__ Wg = W8 + (size_t)blockIdx.x * rows_per_group * 64;
     bool bad = false;
+    struct Pref { Bundle b; PartTerms t; };
+    auto prefetch = [&](uint32_t l) {
+        Pref p{Bundle{0u, 0u}, PartTerms{0u, 0}};
+        if (l < nlevels) {
+            const uint32_t i = levels[6 * l] + wave * WS_IB, ip = levels[6 * l + 2] + wave;
+            if (i < levels[6 * l + 1]) p.b = bundle_fetch(tiny, i, lane);
+            if (ip < levels[6 * l + 3]) p.t = part_fetch(twire, tcoef, parts[4 * ip + 1], lane);
+        }
+        return p;
+    };
+    Pref nx = prefetch(0);
     for (uint32_t l = 0; l < nlevels; l++) {
         const uint32_t t0 = levels[6 * l], t1 = levels[6 * l + 1], p0 = levels[6 * l + 2], p1 = levels[6 * l + 3], b0 = levels[6 * l + 4], b1 = levels[6 * l + 5];
-        // products: out = +-(L R - O), eight items per load round
-        for (uint32_t i = t0 + wave * WS_IB; i < t1; i += NW * WS_IB) {
-            const Bundle b = bundle_fetch(tiny, i, lane);
-            const TinyVals v0 = tiny_load<0>(b, Wg, lane), v1 = tiny_load<1>(b, Wg, lane), v2 = tiny_load<2>(b, Wg, lane), v3 = tiny_load<3>(b, Wg, lane);
-            const TinyVals v4 = tiny_load<4>(b, Wg, lane), v5 = tiny_load<5>(b, Wg, lane), v6 = tiny_load<6>(b, Wg, lane), v7 = tiny_load<7>(b, Wg, lane);
+        const Pref cur = nx;
+        // this wave's first bundle (products: out = +-(L R - O), eight items per load round) and first part (an nBits sum of at most 32 terms):
+        // ONE round of wire loads; the next level's descriptors are requested behind them
+        const uint32_t i0 = t0 + wave * WS_IB, ip0 = p0 + wave;
+        const bool has_b = i0 < t1, has_p = ip0 < p1;
+        if (has_b) {
+            const BundleVals bv = bundle_load(cur.b, Wg, lane);
+            if (!has_p) nx = prefetch(l + 1);
             __builtin_amdgcn_sched_barrier(0);
-            chain_item<0>(b, v0, Wg, lane, bad); chain_item<1>(b, v1, Wg, lane, bad); chain_item<2>(b, v2, Wg, lane, bad); chain_item<3>(b, v3, Wg, lane, bad);
-            chain_item<4>(b, v4, Wg, lane, bad); chain_item<5>(b, v5, Wg, lane, bad); chain_item<6>(b, v6, Wg, lane, bad); chain_item<7>(b, v7, Wg, lane, bad);
+            bundle_finish(cur.b, bv, Wg, lane, bad);
         }
-        // nBits inputs: every wave sums one part (at most 32 terms: one load round) into its LDS slot.  Lane t < 32 holds term t.
-        for (uint32_t i = p0 + wave; i < p1; i += NW) {
-            const uint32_t slot = parts[4 * i], tt = parts[4 * i + 1], nch = parts[4 * i + 2];
-            const uint32_t tw = twire[tt + (lane & 31)];
-            const long long tc = tcoef[tt + (lane & 31)];
-            int v[WS_PART_CHUNKS * WS_CHUNK];
-#pragma unroll
-            for (uint32_t c = 0; c < WS_PART_CHUNKS; c++) {
-                if (c < nch) {
-#pragma unroll
-                    for (uint32_t k = 0; k < WS_CHUNK; k++) v[c * WS_CHUNK + k] = (int)Wg[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)tw, c * WS_CHUNK + k) * 64 + lane];
-                } else {
-#pragma unroll
-                    for (uint32_t k = 0; k < WS_CHUNK; k++) v[c * WS_CHUNK + k] = 0;
-                }
-            }
+        if (has_p) {
+            const uint32_t pslot = parts[4 * ip0], pnch = parts[4 * ip0 + 2];
+            const PartVals pv = part_load(cur.t, pnch, Wg, lane);
+            nx = prefetch(l + 1);
             __builtin_amdgcn_sched_barrier(0);
-            const int clo = (int)(uint32_t)tc, chi = (int)(tc >> 32);
-            long long acc = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < WS_PART_CHUNKS * WS_CHUNK; k++) {      // (terms beyond the part: coefficient 0 or value 0)
-                const long long cf = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(chi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(clo, k));
-                acc += (k < nch * WS_CHUNK ? cf : 0) * (long long)v[k];
-            }
-            s_sum[slot * 64 + lane] = acc;
+            s_sum[pslot * 64 + lane] = part_sum(cur.t, pv, pnch);
+        }
+        if (!has_b && !has_p) nx = prefetch(l + 1);
+        // (levels wider than one bundle / part per wave: the rest, fetched in place)
+        for (uint32_t i = i0 + NW * WS_IB; i < t1; i += NW * WS_IB) {
+            const Bundle b = bundle_fetch(tiny, i, lane);
+            const BundleVals v = bundle_load(b, Wg, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            bundle_finish(b, v, Wg, lane, bad);
+        }
+        for (uint32_t i = ip0 + NW; i < p1; i += NW) {
+            const uint32_t slot = parts[4 * i], nch = parts[4 * i + 2];
+            const PartTerms t = part_fetch(twire, tcoef, parts[4 * i + 1], lane);
+            const PartVals v = part_load(t, nch, Wg, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            s_sum[slot * 64 + lane] = part_sum(t, v, nch);
         }
         if (b0 != b1) {                                          // (the same for every wave of the workgroup)
             __syncthreads();
