@@ -69,15 +69,17 @@ def pmc_traffic(kernel_tag, batch, engine_desc):
     return None, None
 
 
-def valu_per_wave_add():
+def valu_per_wave_add(nbases, nwin):
     """VALU instructions the Z-table kernel issues per wave-addition (64 lanes x one mixed addition), from the newest committed SQ counter
-    pass (profiles/r*_valu_per_add*.json, made by tools/make_valu_per_add.py from SQ_INSTS_VALU of the kernel): a property of the kernel's
-    code, replayed like `traffic` because counters cannot be read inside the timed run."""
+    pass (profiles/r*_valu_per_add*.json, made by tools/make_valu_per_add.py from SQ_INSTS_VALU of the kernel) of the SAME kernel
+    instantiation — number of bases and digit windows must match (c = 17 runs the wide-digit template instance) —, replayed like `traffic`
+    because counters cannot be read inside the timed run.  None for configurations no counter pass was taken on."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_per_add*.json")), reverse=True):
         try:
             d = json.load(open(path))
-            return float(d["instr_per_wave_add"]), "replayed from %s (SQ_INSTS_VALU / wave-additions of a rocprofv3 --pmc pass)" % os.path.relpath(path, ROOT)
+            if d["config"]["nbases"] == nbases and d["config"]["windows"] == nwin:
+                return float(d["instr_per_wave_add"]), "replayed from %s (SQ_INSTS_VALU / wave-additions of a rocprofv3 --pmc pass)" % os.path.relpath(path, ROOT)
         except Exception:
             pass
     return None, None
@@ -94,18 +96,18 @@ def roofline_valu_of(roof, rows, simds):
     (instructions per wave-addition x wave-additions); frac = 4 / that.  Clock: measured live by the kernel itself (two clock stamps of
     a wave in the middle of the launch, gsc_last_kernel_clock); instruction count: replayed from the committed counter pass."""
     clocks = [r[6] for r in rows if r[6] > 0]; nwin = rows[-1][7]; cols, nb = rows[-1][3], rows[-1][4]
-    ipa, src = valu_per_wave_add()
+    ipa, src = valu_per_wave_add(nb, nwin)
     if not clocks or not ipa or not nwin or not simds:
         return None
     mhz = sum(clocks) / len(clocks); ms = roof["launch_ms"]
     wave_adds = nb * nwin * (cols // 64)
     cpi = ms * 1e-3 * mhz * 1e6 * simds / (ipa * wave_adds)
-    valu_ms = nwin * VALU_ONLY_MS_PER_WINDOW_8192 * cols / 8192.0
+    valu_ms = nwin * VALU_ONLY_MS_PER_WINDOW_8192 * (cols / 8192.0) * (nb / 32768.0)
     return {"kernel": roof["kernel"], "bound": "valu-issue", "instr_per_wave_add": ipa, "instr_source": src,
             "wave_adds_per_launch": wave_adds, "windows": nwin, "simds": simds, "clock_mhz": round(mhz, 1),
             "clock_source": "live: shader-clock / 100 MHz-clock stamps of one wave in the middle of each timed launch, averaged",
             "launch_ms": ms, "cycles_per_wave_instr": round(cpi, 4), "issue_floor_cycles": WAVE64_ISSUE_CYCLES, "frac": round(WAVE64_ISSUE_CYCLES / cpi, 4),
-            "valu_only_ms": round(valu_ms, 2), "valu_only_source": "%.1f ms per window at 8192 columns with every gather forced onto one entry (profiles/r02_window_sweep.txt), scaled by the columns" % VALU_ONLY_MS_PER_WINDOW_8192,
+            "valu_only_ms": round(valu_ms, 2), "valu_only_source": "%.1f ms per window of 32 768 bases at 8192 columns with every gather forced onto one entry (profiles/r02_window_sweep.txt), scaled by columns and bases" % VALU_ONLY_MS_PER_WINDOW_8192,
             "miss_clock_loss_ms": round(ms - valu_ms, 2)}
 
 
