@@ -53,7 +53,7 @@ EngineConfig config_from_env() {
     if (c.small_witness < 0 || c.small_witness > 2 || (c.small_witness == 2 && !test_hooks_enabled())) throw std::runtime_error("GSC_SMALL_WITNESS must be 0 or 1");
     if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");
     c.trace_host = getenv("GSC_TRACE_HOST") != nullptr;
-    if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; c.keep_secrets = getenv("GSC_KEEP_SECRETS") != nullptr; }
+    if (test_hooks_enabled()) { c.solver_trace = getenv("GSC_SOLVER_TRACE") != nullptr; c.few_test_abort = getenv("GSC_FEW_TEST_ABORT") != nullptr; c.keep_secrets = getenv("GSC_KEEP_SECRETS") != nullptr; c.z_exp_entry_bits = env_int("GSC_Z_EXP_ENTRY_BITS", 0); }
     if (c.max_batch < 64) c.max_batch = 64;
     c.max_batch = (c.max_batch + 63) / 64 * 64;
     if ((c.window_z && (c.window_z < 4 || c.window_z > MSM_MAX_WINDOW)) || (c.window_w && (c.window_w < 4 || c.window_w > 16))) throw std::runtime_error("GSC_WINDOW_Z must be in [4,17], GSC_WINDOW_W in [4,16]");

@@ -60,6 +60,7 @@ struct EngineConfig {
     bool trace_host = false;     // GSC_TRACE_HOST: host-side timing lines on stderr (InitAlgorithm breakdown, per-chunk enqueue / wait / serialise)
     // diagnostics that change what the device does: honoured only when the test hooks were enabled at load time (test_hooks_enabled())
     bool solver_trace = false;   // GSC_SOLVER_TRACE: per-level clock stamps of the witness kernels
+    int z_exp_entry_bits = 0;    // GSC_Z_EXP_ENTRY_BITS (test hooks; WRONG proofs, timing only): the Z kernel's gathers are confined to the first 2^bits entries of every row
     bool keep_secrets = false;   // GSC_KEEP_SECRETS: skip the end-of-call wipe of key wires / randomness in device memory (shows that the residue check sees them)
     bool few_test_abort = false; // GSC_FEW_TEST_ABORT: the resident witness kernel's barrier never fills (exercises the give-up path)
 };

@@ -98,7 +98,8 @@ void AlgorithmImpl::run_msm(Lane& ln, const MsmCtx& ctx, const MsmSet<AffT>& set
         const size_t Bw = B * (size_t)set.nwin;
         MsmRecodeArgs ra{scalars, set.wrows.p, wires ? 1 : 0, set.nwide, B, set.c, set.nwin, ctx.digits};
         if (!digits_ready) launch_msm_recode(ra, ctx.stream);
-        MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa, timed && !few ? ln.d_clk.p : nullptr};
+        MsmWinArgs a{set.wtable.p, set.c, set.nwin, set.nwide, ctx.digits, B, nslices, per, pa, timed && !few ? ln.d_clk.p : nullptr,
+                     timed && cfg.z_exp_entry_bits > 0 && cfg.z_exp_entry_bits < 31 ? (1u << cfg.z_exp_entry_bits) - 1 : 0u};
         if (timed) HIP_CHECK(hipEventRecord(ln.ev[5], ctx.stream));
         if (few) launch_win_few(a, n_real, ctx.stream);
         else launch_win(a, ctx.stream);

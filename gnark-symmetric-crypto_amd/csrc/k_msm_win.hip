@@ -263,7 +263,8 @@ __device__ __forceinline__ Xyzz9<F> accumulate_window(const MsmWinArgs& a, size_
             // The gather is unconditional (a zero digit fetches entry 0 and drops it): a load inside a branch would have to be
             // waited for at the join, i.e. before the addition it is meant to overlap with.
             const int32_t mag = d < 0 ? -d : d;
-            const RawAff<F> e = load_raw<F>(table + ((kk + i) * D + (size_t)(mag ? mag - 1 : 0)) * (2 * F::WORDS));
+            const size_t ent = a.exp_entry_mask ? (size_t)((uint32_t)(mag ? mag - 1 : 0) & a.exp_entry_mask) : (size_t)(mag ? mag - 1 : 0);      // (exp_entry_mask: timing experiment only)
+            const RawAff<F> e = load_raw<F>(table + ((kk + i) * D + ent) * (2 * F::WORDS));
             if (dp) acc = C::template madd<EXACT>(acc, unpack_aff(pend, dp < 0));
             pend = e; dp = d;
         }

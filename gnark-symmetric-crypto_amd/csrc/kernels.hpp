@@ -199,6 +199,9 @@ struct MsmWinArgs {
     // diagnostics (bench.py's VALU roofline): the workgroup in the middle of the grid stamps {100 MHz clock, shader clock} when it starts and
     // when it ends -> clk[0..3]; their ratio is the shader clock the launch really ran at (the chip is power-limited).  nullptr: no stamps.
     unsigned long long* clk = nullptr;
+    // TEST HOOK (timing experiment, WRONG sums): every gather's entry index is masked to this many bits, i.e. the kernel does the same arithmetic over rows of
+    // 2^bits entries — the L2 hit rate it would have with that many lanes per entry in flight.  0 = off.
+    uint32_t exp_entry_mask = 0;
 };
 void launch_msm_win_g1(const MsmWinArgs& a, hipStream_t s);
 void launch_msm_win_g2(const MsmWinArgs& a, hipStream_t s);
