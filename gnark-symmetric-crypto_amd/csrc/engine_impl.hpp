@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 #include "wit_small.hpp"
 #include <atomic>
+#include <cstring>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -28,6 +29,17 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     void alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; if (count) HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T))); }
     void upload(const T* src, size_t count, hipStream_t s) { HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s)); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// page-locked host memory: the staging buffers of a lane (uploads and downloads are then real asynchronous DMA, not driver-staged copies)
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr; size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete; PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void alloc(size_t count) { if (p) { (void)hipHostFree(p); p = nullptr; } n = count; if (count) { HIP_CHECK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault)); memset(p, 0, count * sizeof(T)); } }
     size_t bytes() const { return n * sizeof(T); }
 };
 
@@ -118,6 +130,8 @@ class AlgorithmImpl {
         hipEvent_t ev_few = nullptr;    // completion of this lane's latest k_solver_few launch (FewSolverChain)
         hipEvent_t ev[7] = {};          // 0..4 stage boundaries, 5..6 bracket the dominant kernel (Z-table MSM gather-accumulate)
         float stage_ms[4] = {0, 0, 0, 0}; float msm_z_kernel_ms = 0; size_t last_batch = 0;
+        // pinned staging: inputs / randomness / masks up, proof coordinates / flags / status / commitment points and the small result words down
+        PinnedBuf<uint8_t> h_in, h_rs, h_mask, h_out, h_flags, h_cpts; PinnedBuf<uint32_t> h_status; PinnedBuf<GlvSplit> h_glv; PinnedBuf<unsigned long long> h_words;
         KernelStat stat;                // of the chunk this lane proved last
         DevBuf<unsigned long long> d_clk;      // clock stamps of the Z kernel (MsmWinArgs::clk); [4 ..16): of the three transform kernels (GSC_TRACE_HOST)
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
@@ -151,7 +165,7 @@ class AlgorithmImpl {
 
     std::unique_ptr<SolverProgram> init_program(const R1csFile& cs);
 
-    static void pack_inputs(const ProofRequest* reqs, size_t n, size_t B, std::vector<uint8_t>& h_in, std::vector<uint8_t>& h_rs);
+    static void pack_inputs(const ProofRequest* reqs, size_t n, size_t B, uint8_t* h_in, uint8_t* h_rs);      // 176 B and 64 B per column
 
     // Which wires are bits?  Nothing in an R1CS says so, but it is a property of the circuit, not of the statement: solve 64
     // pseudo-random statements once and call a wire a bit when it is 0 or 1 in all of them.  This is only a PREDICTION used to

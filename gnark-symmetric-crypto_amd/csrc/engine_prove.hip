@@ -173,31 +173,27 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     ln.n_real = n;
     const bool trace = cfg.trace_host;
     const auto tc0 = std::chrono::steady_clock::now();
-    struct Wiper { std::vector<uint8_t>& v; ~Wiper() { if (!v.empty()) explicit_bzero(v.data(), v.size()); } };      // host staging copies of key and randomness
-    std::vector<uint8_t> h_in, h_rs; Wiper wipe_in{h_in}, wipe_rs{h_rs};
+    // staging is the lane's pinned memory; what it holds of the statements' secrets (keys, randomness, masks) is cleared when the call leaves, however it leaves
+    struct StagingWiper { Lane& l; size_t B; ~StagingWiper() { explicit_bzero(l.h_in.p, 176 * B); explicit_bzero(l.h_rs.p, 64 * B); explicit_bzero(l.h_glv.p, l.h_glv.bytes()); if (l.h_mask.p) explicit_bzero(l.h_mask.p, 32 * B); } } wipe_staging{ln, B};
+    uint8_t* const h_in = ln.h_in.p; uint8_t* const h_rs = ln.h_rs.p; GlvSplit* const h_glv = ln.h_glv.p;
     pack_inputs(reqs, n, B, h_in, h_rs);
-    ln.d_inputs.upload(h_in.data(), h_in.size(), ln.stream);
-    ln.d_rs.upload(h_rs.data(), h_rs.size(), ln.stream);
-    std::vector<GlvSplit> h_glv;                                     // (lives as long as the other staging vectors of the call)
-    struct GlvWiper { std::vector<GlvSplit>& v; ~GlvWiper() { if (!v.empty()) explicit_bzero(v.data(), v.size() * sizeof(GlvSplit)); } } wipe_glv{h_glv};
+    ln.d_inputs.upload(h_in, 176 * B, ln.stream);
+    ln.d_rs.upload(h_rs, 64 * B, ln.stream);
     if (n <= (size_t)cfg.few_max && cfg.few_path && B == 64) {      // latency path: the two halves of s and r for k_fin_scalarmul_few
-        h_glv.resize(2 * n);
         for (size_t i = 0; i < n; i++) for (int role = 0; role < 2; role++) {
-            uint32_t w[8]; memcpy(w, h_rs.data() + 64 * i + (role == 0 ? 32 : 0), 32);
+            uint32_t w[8]; memcpy(w, h_rs + 64 * i + (role == 0 ? 32 : 0), 32);
             if (!glv_split(w, h_glv[2 * i + role])) throw std::runtime_error("internal: scalar split out of range");
         }
-        ln.d_glv.upload(h_glv.data(), h_glv.size(), ln.stream);
+        ln.d_glv.upload(h_glv, 2 * n, ln.stream);
     }
     HIP_CHECK(hipMemsetAsync(ln.d_flags.p, 0, ln.d_flags.bytes(), ln.stream));
     HIP_CHECK(hipEventRecord(ln.ev[0], ln.stream));
     // 1. witness
     if (cipher == CHACHA20) launch_assign_chacha(ln.d_inputs.p, ln.d_W.p, B, ln.stream);
     else launch_assign_aes(ln.d_inputs.p, cipher == AES_128 ? 16 : 32, ln.d_W.p, B, ln.stream);
-    std::vector<uint8_t> h_mask; Wiper wipe_mask{h_mask};
     if (has_commitment) {
-        h_mask.resize(32 * B);
-        for (size_t i = 0; i < B; i++) memcpy(h_mask.data() + 32 * i, reqs[i < n ? i : n - 1].mask, 32);
-        ln.d_mask_in.upload(h_mask.data(), h_mask.size(), ln.stream);
+        for (size_t i = 0; i < B; i++) memcpy(ln.h_mask.p + 32 * i, reqs[i < n ? i : n - 1].mask, 32);
+        ln.d_mask_in.upload(ln.h_mask.p, 32 * B, ln.stream);
     }
     launch_prep_rs(ln.d_rs.p, ln.d_W.p, n_wires, B, has_commitment ? ln.d_mask_in.p : nullptr, ln.d_mask.p, ln.stream);
     HIP_CHECK(hipMemsetAsync(ln.d_status.p, 0xFF, B * 4, ln.stream));
@@ -252,7 +248,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
             } else launch_solver_level(sa, level_width[l], ln.stream);
         }
     };
-    std::vector<uint8_t> h_cpts;
+    uint8_t* const h_cpts = ln.h_cpts.p;
     if (latency_call) HIP_CHECK(hipEventRecord(ln.ev[5], ln.stream));      // dominant kernel of a latency-path call: the witness solver
     if (has_commitment) {
         // Groth16 commitment (gnark "BSB22"): solve up to the commitment hint, D = sum w_j * Basis_j over the
@@ -263,7 +259,6 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         flush_horner_g1(ln, B, ln.stream);
         launch_points_to_affine_be(ln.d_sumD.p, B, ln.d_cpts.p, ln.d_flags.p, 8, ln.stream);
         launch_challenge_from_point(ln.d_cpts.p, ln.d_commit.p, B, ln.stream);
-        h_cpts.resize(128 * B);
         run_levels(commit_level, n_levels);
     } else if (small_call) {
         HIP_CHECK(hipMemsetAsync(ln.d_wsflag.p, 0, 4, ln.stream));
@@ -377,16 +372,18 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     launch_fin_combine(ln.d_sumB2.p, ln.d_sumK.p, ln.d_sumZ.p, eval ? ln.d_sumC.p : nullptr, ln.d_tmp.p, B, ln.d_out.p, ln.d_flags.p, ln.stream);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ln.ev[4], ln.stream));
-    std::vector<uint8_t> h_out(256 * B), h_flags(ln.d_flags.n); std::vector<uint32_t> h_status(B);
-    HIP_CHECK(hipMemcpyAsync(h_out.data(), ln.d_out.p, h_out.size(), hipMemcpyDeviceToHost, ln.stream));
-    HIP_CHECK(hipMemcpyAsync(h_flags.data(), ln.d_flags.p, h_flags.size(), hipMemcpyDeviceToHost, ln.stream));
-    HIP_CHECK(hipMemcpyAsync(h_status.data(), ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
-    if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts.data(), ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
-    uint32_t h_fsync[2] = {0, 0}, h_wsflag = 0;
+    uint8_t* const h_out = ln.h_out.p; uint8_t* const h_flags = ln.h_flags.p; uint32_t* const h_status = ln.h_status.p;
+    HIP_CHECK(hipMemcpyAsync(h_out, ln.d_out.p, 256 * B, hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipMemcpyAsync(h_flags, ln.d_flags.p, (B + 3) / 4 * 4, hipMemcpyDeviceToHost, ln.stream));
+    HIP_CHECK(hipMemcpyAsync(h_status, ln.d_status.p, B * 4, hipMemcpyDeviceToHost, ln.stream));
+    if (has_commitment) HIP_CHECK(hipMemcpyAsync(h_cpts, ln.d_cpts.p, 128 * B, hipMemcpyDeviceToHost, ln.stream));      // commitment | its proof of knowledge
+    // the small result words, in the lane's pinned block: [0] the resident solver's two sync words, [1] the small-integer path's flag, [2 .. 18) clock stamps
+    unsigned long long* const hw = ln.h_words.p; memset(hw, 0, ln.h_words.bytes());
+    uint32_t* const h_fsync = reinterpret_cast<uint32_t*>(hw); uint32_t& h_wsflag = *reinterpret_cast<uint32_t*>(hw + 1);
     if (few_solver) HIP_CHECK(hipMemcpyAsync(h_fsync, ln.d_fsync.p, 8, hipMemcpyDeviceToHost, ln.stream));
     if (small_call) HIP_CHECK(hipMemcpyAsync(&h_wsflag, ln.d_wsflag.p, 4, hipMemcpyDeviceToHost, ln.stream));
     wipe_secrets(ln, B, small_call);      // behind the last kernel of the chunk, inside the wait below
-    unsigned long long h_clk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long* const h_clk = hw + 2;
     if (!latency_call) HIP_CHECK(hipMemcpyAsync(h_clk, ln.d_clk.p, trace ? 128 : 32, hipMemcpyDeviceToHost, ln.stream));
     const auto tc1 = std::chrono::steady_clock::now();
     HIP_CHECK(hipStreamSynchronize(ln.stream));
@@ -416,7 +413,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         last_stat = st;
     }
     for (size_t i = 0; i < n; i++)
-        serialize(h_out.data() + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts.data() + 64 * i : nullptr, has_commitment ? h_cpts.data() + 64 * B + 64 * i : nullptr, results[i]);
+        serialize(h_out + 256 * i, h_flags[i], h_status[i], has_commitment ? h_cpts + 64 * i : nullptr, has_commitment ? h_cpts + 64 * B + 64 * i : nullptr, results[i]);
     if (trace) {
         const auto tc3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

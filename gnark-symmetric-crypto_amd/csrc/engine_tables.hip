@@ -132,16 +132,16 @@ void AlgorithmImpl::init_small(const SolverProgram& sp) {
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
-void AlgorithmImpl::pack_inputs(const ProofRequest* reqs, size_t n, size_t B, std::vector<uint8_t>& h_in, std::vector<uint8_t>& h_rs) {
-    h_in.assign(176 * B, 0); h_rs.assign(64 * B, 0);
+void AlgorithmImpl::pack_inputs(const ProofRequest* reqs, size_t n, size_t B, uint8_t* h_in, uint8_t* h_rs) {
+    memset(h_in, 0, 176 * B); memset(h_rs, 0, 64 * B);
     for (size_t i = 0; i < B; i++) {
         const ProofRequest& q = reqs[i < n ? i : n - 1];
-        uint8_t* rec = h_in.data() + 176 * i;
+        uint8_t* rec = h_in + 176 * i;
         memcpy(rec, q.key, q.keylen);
         memcpy(rec + 32, q.nonce, 12);
         rec[44] = (uint8_t)q.counter; rec[45] = (uint8_t)(q.counter >> 8); rec[46] = (uint8_t)(q.counter >> 16); rec[47] = (uint8_t)(q.counter >> 24);
         memcpy(rec + 48, q.plaintext, 64); memcpy(rec + 112, q.ciphertext, 64);
-        memcpy(h_rs.data() + 64 * i, q.r, 32); memcpy(h_rs.data() + 64 * i + 32, q.s, 32);
+        memcpy(h_rs + 64 * i, q.r, 32); memcpy(h_rs + 64 * i + 32, q.s, 32);
     }
 }
 
@@ -167,7 +167,7 @@ void AlgorithmImpl::calibrate() {
         else aes_ctr_xor_stream(q.key, q.keylen, q.nonce, q.counter, q.plaintext, q.ciphertext, 64);
         q.r[0] = 3; q.s[0] = 5; q.mask[0] = 7;
     }
-    std::vector<uint8_t> h_in, h_rs; pack_inputs(reqs.data(), B, B, h_in, h_rs);
+    std::vector<uint8_t> h_in(176 * B), h_rs(64 * B); pack_inputs(reqs.data(), B, B, h_in.data(), h_rs.data());
     DevBuf<uint8_t> d_inputs(h_in.size()), d_rs(h_rs.size()), d_mask_in(32 * B); DevBuf<uint32_t> d_status(B);
     DevBuf<fe> d_W((n_wires + 4) * B), d_A(n_constraints * B), d_B(n_constraints * B), d_C(n_constraints * B), d_mask(B), d_commit(B);
     d_inputs.upload(h_in.data(), h_in.size(), stream); d_rs.upload(h_rs.data(), h_rs.size(), stream);
@@ -473,6 +473,7 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
+    ln.h_in.alloc(176 * B); ln.h_rs.alloc(64 * B); ln.h_glv.alloc(2 * MSM_FEW_PROOFS); ln.h_out.alloc(256 * B); ln.h_flags.alloc((B + 3) / 4 * 4); ln.h_status.alloc(B); ln.h_words.alloc(24);
     ln.d_clk.alloc(16); HIP_CHECK(hipMemsetAsync(ln.d_clk.p, 0, 128, ln.stream));
     ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2); ln.d_glv.alloc(2 * MSM_FEW_PROOFS);
     // (the buffers that will hold secrets start out clean, so that "nothing of a call is left" can be checked from the first call on)
@@ -536,6 +537,7 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     ln.d_sumA.alloc(B); ln.d_sumB1.alloc(B); ln.d_sumK.alloc(B); ln.d_sumZ.alloc(B); ln.d_sumC.alloc(B); ln.d_sumB2.alloc(B); ln.d_tmp.alloc(2 * B);
     if (has_commitment) {
         ln.d_mask_in.alloc(32 * B); ln.d_mask.alloc(B); ln.d_commit.alloc(B); ln.d_cpts.alloc(128 * B); ln.d_sumD.alloc(B); ln.d_sumPok.alloc(B);
+        ln.h_mask.alloc(32 * B); ln.h_cpts.alloc(128 * B);
         HIP_CHECK(hipMemsetAsync(ln.d_mask_in.p, 0, ln.d_mask_in.bytes(), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_mask.p, 0, ln.d_mask.bytes(), ln.stream));
     }
 }
