@@ -71,15 +71,16 @@ def pmc_traffic(kernel_tag, batch, engine_desc):
 
 def valu_per_wave_add(nbases, nwin):
     """VALU instructions the Z-table kernel issues per wave-addition (64 lanes x one mixed addition), from the newest committed SQ counter
-    pass (profiles/r*_valu_per_add*.json, made by tools/make_valu_per_add.py from SQ_INSTS_VALU of the kernel) of the SAME kernel
-    instantiation — number of bases and digit windows must match (c = 17 runs the wide-digit template instance) —, replayed like `traffic`
-    because counters cannot be read inside the timed run.  None for configurations no counter pass was taken on."""
+    pass (profiles/r*_valu_per_add*.json, made by tools/make_valu_per_add.py from SQ_INSTS_VALU of the kernel), replayed like `traffic`
+    because counters cannot be read inside the timed run.  The pass must be of the same Z set (number of bases: a circuit no pass was
+    taken on gets no figure); a different digit width runs the same gather-accumulate loop (the count is per addition) and says so."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_per_add*.json")), reverse=True):
         try:
             d = json.load(open(path))
-            if d["config"]["nbases"] == nbases and d["config"]["windows"] == nwin:
-                return float(d["instr_per_wave_add"]), "replayed from %s (SQ_INSTS_VALU / wave-additions of a rocprofv3 --pmc pass)" % os.path.relpath(path, ROOT)
+            if d["config"]["nbases"] == nbases:
+                note = "" if d["config"]["windows"] == nwin else "; counted on the %d-window launch, this run has %d windows (same loop, other digit format)" % (d["config"]["windows"], nwin)
+                return float(d["instr_per_wave_add"]), "replayed from %s (SQ_INSTS_VALU / wave-additions of a rocprofv3 --pmc pass%s)" % (os.path.relpath(path, ROOT), note)
         except Exception:
             pass
     return None, None
