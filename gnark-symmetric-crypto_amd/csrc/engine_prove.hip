@@ -263,7 +263,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     } else if (small_call) {
         HIP_CHECK(hipMemsetAsync(ln.d_wsflag.p, 0, 4, ln.stream));
         launch_wit_narrow(ln.d_W.p, B, n_inputs, ln.d_W8.p, small.rows_per_group, ln.d_wsflag.p, ln.stream);
-        launch_wit_chain(WitChainArgs{ws_tiny.p, ws_parts.p, ws_bits.p, ws_twire.p, ws_tcoef.p, ws_levels.p, small.n_levels, ln.d_W8.p, small.rows_per_group, ln.d_wsflag.p, small.max_slots, small.max_fresh}, B / 64, ln.stream);
+        launch_wit_chain(WitChainArgs{ws_tiny.p, ws_parts.p, ws_bits.p, ws_twire.p, ws_tcoef.p, ws_levels.p, small.n_levels, ln.d_W8.p, small.rows_per_group, ln.d_wsflag.p}, B / 64, 512 * (size_t)small.max_slots, ln.stream);
         const uint32_t per_chunk = 4 * WS_IB;
         launch_wit_rows(WitRowsArgs{ws_rtiny.p, small.n_rtiny, per_chunk, (small.n_rtiny + per_chunk - 1) / per_chunk, ws_rgen.p, small.n_rgen, ws_rtwire.p, ws_rtcoef.p, ln.d_W8.p, small.rows_per_group,
                                     ln.d_A8.p, ln.d_B8.p, ln.d_C8.p, n_constraints, ln.d_A.p, ln.d_B.p, ln.d_C.p, B, ln.d_status.p, ln.d_wsflag.p}, B / 64, ln.stream);

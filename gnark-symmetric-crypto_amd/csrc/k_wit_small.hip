@@ -24,16 +24,11 @@ __device__ __forceinline__ Bundle bundle_fetch(const uint32_t* __restrict__ item
 }
 template <int K, int F> __device__ __forceinline__ uint32_t bfield(const Bundle& b) { return (uint32_t)__builtin_amdgcn_readlane((int)(K < 4 ? b.lo : b.hi), 16 * (K & 3) + F); }
 struct TinyVals { int v[6]; };
-// one wire value of this lane's proof: from memory, or (chain only: WS_SRC_FRESH, wave-uniform) from the LDS copy of the previous level's outputs
-__device__ __forceinline__ int wire_load(uint32_t w, const int8_t* __restrict__ Wg, const int8_t* fresh, uint32_t lane) {
-    if (fresh && (w & WS_SRC_FRESH)) return (int)fresh[(w & ~WS_SRC_FRESH) * 64 + lane];
-    return (int)Wg[(size_t)w * 64 + lane];
-}
-template <int K> __device__ __forceinline__ TinyVals tiny_load(const Bundle& b, const int8_t* __restrict__ Wg, uint32_t lane, const int8_t* fresh = nullptr) {
+template <int K> __device__ __forceinline__ TinyVals tiny_load(const Bundle& b, const int8_t* __restrict__ Wg, uint32_t lane) {
     TinyVals t;
-    t.v[0] = wire_load(bfield<K, 2>(b), Wg, fresh, lane); t.v[1] = wire_load(bfield<K, 3>(b), Wg, fresh, lane);
-    t.v[2] = wire_load(bfield<K, 4>(b), Wg, fresh, lane); t.v[3] = wire_load(bfield<K, 5>(b), Wg, fresh, lane);
-    t.v[4] = wire_load(bfield<K, 6>(b), Wg, fresh, lane); t.v[5] = wire_load(bfield<K, 7>(b), Wg, fresh, lane);
+    t.v[0] = (int)Wg[(size_t)bfield<K, 2>(b) * 64 + lane]; t.v[1] = (int)Wg[(size_t)bfield<K, 3>(b) * 64 + lane];
+    t.v[2] = (int)Wg[(size_t)bfield<K, 4>(b) * 64 + lane]; t.v[3] = (int)Wg[(size_t)bfield<K, 5>(b) * 64 + lane];
+    t.v[4] = (int)Wg[(size_t)bfield<K, 6>(b) * 64 + lane]; t.v[5] = (int)Wg[(size_t)bfield<K, 7>(b) * 64 + lane];
     return t;
 }
 // L = c0 v0 + c1 v1, R, O alike (|c| < 2^28, v in {-1, 0, 1})
@@ -42,30 +37,25 @@ template <int K> __device__ __forceinline__ void tiny_sums(const Bundle& b, cons
     R = (int)bfield<K, 10>(b) * t.v[2] + (int)bfield<K, 11>(b) * t.v[3];
     O = (int)bfield<K, 12>(b) * t.v[4] + (int)bfield<K, 13>(b) * t.v[5];
 }
-template <int K> __device__ __forceinline__ int8_t chain_value(const Bundle& b, const TinyVals& t, bool& bad) {
+template <int K> __device__ __forceinline__ void chain_item(const Bundle& b, const TinyVals& t, int8_t* __restrict__ Wg, uint32_t lane, bool& bad) {
     int L, R, O; tiny_sums<K>(b, t, L, R, O);
     long long w = (long long)L * R - O;
     if (bfield<K, 0>(b) & WS_F_NEG) w = -w;
     bad |= (unsigned long long)(w + 1) > 2ull;                         // the solved wire was predicted to stay in {-1, 0, 1}
-    return (int8_t)w;
-}
-// the output goes to memory (for the levels after the next one, and for the kernels after this one) and to the LDS copy the next level reads
-template <int K> __device__ __forceinline__ void chain_store(const Bundle& b, int8_t w, int8_t* __restrict__ Wg, int8_t* fresh, uint32_t lane) {
-    Wg[(size_t)bfield<K, 1>(b) * 64 + lane] = w;                       // (padding items write 0 to the scratch row / the slot behind the level's outputs)
-    fresh[bfield<K, 14>(b) * 64 + lane] = w;
+    Wg[(size_t)bfield<K, 1>(b) * 64 + lane] = (int8_t)w;               // (padding items write 0 to the scratch row)
 }
 
 // the terms of one part of an nBits sum: lane t < 32 holds term t
 struct PartTerms { uint32_t tw; long long tc; };
 __device__ __forceinline__ PartTerms part_fetch(const uint32_t* __restrict__ twire, const long long* __restrict__ tcoef, uint32_t tt, uint32_t lane) { return PartTerms{twire[tt + (lane & 31)], tcoef[tt + (lane & 31)]}; }
 struct PartVals { int v[WS_PART_CHUNKS * WS_CHUNK]; };
-__device__ __forceinline__ PartVals part_load(const PartTerms& t, uint32_t nch, const int8_t* __restrict__ Wg, const int8_t* fresh, uint32_t lane) {
+__device__ __forceinline__ PartVals part_load(const PartTerms& t, uint32_t nch, const int8_t* __restrict__ Wg, uint32_t lane) {
     PartVals r;
 #pragma unroll
     for (uint32_t c = 0; c < WS_PART_CHUNKS; c++) {
         if (c < nch) {
 #pragma unroll
-            for (uint32_t k = 0; k < WS_CHUNK; k++) r.v[c * WS_CHUNK + k] = wire_load((uint32_t)__builtin_amdgcn_readlane((int)t.tw, c * WS_CHUNK + k), Wg, fresh, lane);
+            for (uint32_t k = 0; k < WS_CHUNK; k++) r.v[c * WS_CHUNK + k] = (int)Wg[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)t.tw, c * WS_CHUNK + k) * 64 + lane];
         } else {
 #pragma unroll
             for (uint32_t k = 0; k < WS_CHUNK; k++) r.v[c * WS_CHUNK + k] = 0;
@@ -84,23 +74,13 @@ __device__ __forceinline__ long long part_sum(const PartTerms& t, const PartVals
     return acc;
 }
 struct BundleVals { TinyVals v0, v1, v2, v3, v4, v5, v6, v7; };
-__device__ __forceinline__ BundleVals bundle_load(const Bundle& b, const int8_t* __restrict__ Wg, const int8_t* fresh, uint32_t lane) {
-    return BundleVals{tiny_load<0>(b, Wg, lane, fresh), tiny_load<1>(b, Wg, lane, fresh), tiny_load<2>(b, Wg, lane, fresh), tiny_load<3>(b, Wg, lane, fresh),
-                      tiny_load<4>(b, Wg, lane, fresh), tiny_load<5>(b, Wg, lane, fresh), tiny_load<6>(b, Wg, lane, fresh), tiny_load<7>(b, Wg, lane, fresh)};
+__device__ __forceinline__ BundleVals bundle_load(const Bundle& b, const int8_t* __restrict__ Wg, uint32_t lane) {
+    return BundleVals{tiny_load<0>(b, Wg, lane), tiny_load<1>(b, Wg, lane), tiny_load<2>(b, Wg, lane), tiny_load<3>(b, Wg, lane), tiny_load<4>(b, Wg, lane), tiny_load<5>(b, Wg, lane), tiny_load<6>(b, Wg, lane), tiny_load<7>(b, Wg, lane)};
 }
-// The stores of the PREVIOUS level must have been acknowledged before this level's barrier (the level after this one reads them from memory): they
-// were issued a whole level ago, so waiting for them here — after this level's loads and arithmetic, before its own stores — costs nothing, and the
-// barrier itself only waits for LDS.
-__device__ __forceinline__ void drain_memory_ops() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void bundle_finish(const Bundle& b, const BundleVals& v, int8_t* __restrict__ Wg, int8_t* fresh_out, uint32_t lane, bool& bad) {
-    const int8_t w0 = chain_value<0>(b, v.v0, bad), w1 = chain_value<1>(b, v.v1, bad), w2 = chain_value<2>(b, v.v2, bad), w3 = chain_value<3>(b, v.v3, bad);
-    const int8_t w4 = chain_value<4>(b, v.v4, bad), w5 = chain_value<5>(b, v.v5, bad), w6 = chain_value<6>(b, v.v6, bad), w7 = chain_value<7>(b, v.v7, bad);
-    drain_memory_ops();
-    chain_store<0>(b, w0, Wg, fresh_out, lane); chain_store<1>(b, w1, Wg, fresh_out, lane); chain_store<2>(b, w2, Wg, fresh_out, lane); chain_store<3>(b, w3, Wg, fresh_out, lane);
-    chain_store<4>(b, w4, Wg, fresh_out, lane); chain_store<5>(b, w5, Wg, fresh_out, lane); chain_store<6>(b, w6, Wg, fresh_out, lane); chain_store<7>(b, w7, Wg, fresh_out, lane);
+__device__ __forceinline__ void bundle_finish(const Bundle& b, const BundleVals& v, int8_t* __restrict__ Wg, uint32_t lane, bool& bad) {
+    chain_item<0>(b, v.v0, Wg, lane, bad); chain_item<1>(b, v.v1, Wg, lane, bad); chain_item<2>(b, v.v2, Wg, lane, bad); chain_item<3>(b, v.v3, Wg, lane, bad);
+    chain_item<4>(b, v.v4, Wg, lane, bad); chain_item<5>(b, v.v5, Wg, lane, bad); chain_item<6>(b, v.v6, Wg, lane, bad); chain_item<7>(b, v.v7, Wg, lane, bad);
 }
-// workgroup barrier that orders LDS only (memory operations are drained where it matters: drain_memory_ops)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // One workgroup per group of 64 proofs walks every level that produces wires; NW waves share a level's items.
 // A level costs its dependent memory round trips: wire loads, then the stores' acknowledgement before the barrier.  The descriptors of a
@@ -108,12 +88,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // wave never has more than one of each per level — so that nothing but the wire loads stands between a barrier and the arithmetic.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_wit_chain(const uint32_t* __restrict__ tiny, const uint32_t* __restrict__ parts, const uint32_t* __restrict__ bits, const uint32_t* __restrict__ twire,
-                                                       const long long* __restrict__ tcoef, const uint32_t* __restrict__ levels, uint32_t nlevels, int8_t* __restrict__ W8, size_t rows_per_group, uint32_t* __restrict__ flag,
-                                                       uint32_t max_slots, uint32_t max_fresh) {
-    extern __shared__ long long s_sum[];                     // [slot][lane]: the partial sums of the level's nBits inputs; behind them: two copies of a level's outputs [slot][lane] (bytes)
+                                                       const long long* __restrict__ tcoef, const uint32_t* __restrict__ levels, uint32_t nlevels, int8_t* __restrict__ W8, size_t rows_per_group, uint32_t* __restrict__ flag) {
+    extern __shared__ long long s_sum[];                     // [slot][lane]: the partial sums of the level's nBits inputs
     const uint32_t lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
     int8_t* __restrict__ Wg = W8 + (size_t)blockIdx.x * rows_per_group * 64;
-    int8_t* const fresh0 = reinterpret_cast<int8_t*>(s_sum + (size_t)max_slots * 64);
     bool bad = false;
     struct Pref { Bundle b; PartTerms t; };
     auto prefetch = [&](uint32_t l) {
@@ -129,21 +107,19 @@ __global__ __launch_bounds__(64 * NW) void k_wit_chain(const uint32_t* __restric
     for (uint32_t l = 0; l < nlevels; l++) {
         const uint32_t t0 = levels[6 * l], t1 = levels[6 * l + 1], p0 = levels[6 * l + 2], p1 = levels[6 * l + 3], b0 = levels[6 * l + 4], b1 = levels[6 * l + 5];
         const Pref cur = nx;
-        const int8_t* const fresh_in = fresh0 + (size_t)((l + 1) & 1) * max_fresh * 64;      // what level l - 1 produced (level 0 has no fresh terms)
-        int8_t* const fresh_out = fresh0 + (size_t)(l & 1) * max_fresh * 64;
         // this wave's first bundle (products: out = +-(L R - O), eight items per load round) and first part (an nBits sum of at most 32 terms):
         // ONE round of wire loads; the next level's descriptors are requested behind them
         const uint32_t i0 = t0 + wave * WS_IB, ip0 = p0 + wave;
         const bool has_b = i0 < t1, has_p = ip0 < p1;
         if (has_b) {
-            const BundleVals bv = bundle_load(cur.b, Wg, fresh_in, lane);
+            const BundleVals bv = bundle_load(cur.b, Wg, lane);
             if (!has_p) nx = prefetch(l + 1);
             __builtin_amdgcn_sched_barrier(0);
-            bundle_finish(cur.b, bv, Wg, fresh_out, lane, bad);
+            bundle_finish(cur.b, bv, Wg, lane, bad);
         }
         if (has_p) {
             const uint32_t pslot = parts[4 * ip0], pnch = parts[4 * ip0 + 2];
-            const PartVals pv = part_load(cur.t, pnch, Wg, fresh_in, lane);
+            const PartVals pv = part_load(cur.t, pnch, Wg, lane);
             nx = prefetch(l + 1);
             __builtin_amdgcn_sched_barrier(0);
             s_sum[pslot * 64 + lane] = part_sum(cur.t, pv, pnch);
@@ -152,31 +128,29 @@ __global__ __launch_bounds__(64 * NW) void k_wit_chain(const uint32_t* __restric
         // (levels wider than one bundle / part per wave: the rest, fetched in place)
         for (uint32_t i = i0 + NW * WS_IB; i < t1; i += NW * WS_IB) {
             const Bundle b = bundle_fetch(tiny, i, lane);
-            const BundleVals v = bundle_load(b, Wg, fresh_in, lane);
+            const BundleVals v = bundle_load(b, Wg, lane);
             __builtin_amdgcn_sched_barrier(0);
-            bundle_finish(b, v, Wg, fresh_out, lane, bad);
+            bundle_finish(b, v, Wg, lane, bad);
         }
         for (uint32_t i = ip0 + NW; i < p1; i += NW) {
             const uint32_t slot = parts[4 * i], nch = parts[4 * i + 2];
             const PartTerms t = part_fetch(twire, tcoef, parts[4 * i + 1], lane);
-            const PartVals v = part_load(t, nch, Wg, fresh_in, lane);
+            const PartVals v = part_load(t, nch, Wg, lane);
             __builtin_amdgcn_sched_barrier(0);
             s_sum[slot * 64 + lane] = part_sum(t, v, nch);
         }
         if (b0 != b1) {                                          // (the same for every wave of the workgroup)
-            lds_barrier();
+            __syncthreads();
             for (uint32_t i = b0 + wave; i < b1; i += NW) {
-                const uint32_t out = bits[4 * i], sl = bits[4 * i + 1], bb = bits[4 * i + 2], fs = bits[4 * i + 3];
+                const uint32_t out = bits[4 * i], sl = bits[4 * i + 1], bb = bits[4 * i + 2];
                 const uint32_t slot0 = sl & 0xFFFFu, np = sl >> 16, sh = bb & 0xFFu, nb = bb >> 8;
                 long long s = 0;
                 for (uint32_t k = 0; k < np; k++) s += s_sum[(slot0 + k) * 64 + lane];
                 bad |= s < 0;                                    // gnark's hint takes the bits of the canonical residue: r + s, not ours
-                drain_memory_ops();
-                for (uint32_t b = 0; b < nb; b++) { const int8_t v = (int8_t)((s >> (sh + b)) & 1); Wg[(size_t)(out + b) * 64 + lane] = v; fresh_out[(fs + b) * 64 + lane] = v; }
+                for (uint32_t b = 0; b < nb; b++) Wg[(size_t)(out + b) * 64 + lane] = (int8_t)((s >> (sh + b)) & 1);
             }
         }
-        drain_memory_ops();                                      // (waves that stored nothing in this level: their stores of the previous level, their prefetches)
-        lds_barrier();                                           // the level's outputs are in LDS for the next level; in memory for the one after it
+        __syncthreads();                                         // the level's wires are visible to every wave of the workgroup
     }
     if (bad) atomicOr(flag, 1u);
 }
@@ -296,9 +270,9 @@ __global__ void k_coeff_small(const fe* __restrict__ coeff, size_t n, long long*
 
 }  // namespace
 
-void launch_wit_chain(const WitChainArgs& a, size_t groups, hipStream_t s) {
+void launch_wit_chain(const WitChainArgs& a, size_t groups, size_t lds_bytes, hipStream_t s) {
     if (!groups || !a.nlevels) return;
-    hipLaunchKernelGGL((k_wit_chain<16>), dim3((unsigned)groups), dim3(64 * 16), 512 * (size_t)a.max_slots + 128 * (size_t)a.max_fresh, s, a.tiny, a.parts, a.bits, a.twire, a.tcoef, a.levels, a.nlevels, a.W8, a.rows_per_group, a.flag, a.max_slots, a.max_fresh);
+    hipLaunchKernelGGL((k_wit_chain<16>), dim3((unsigned)groups), dim3(64 * 16), lds_bytes, s, a.tiny, a.parts, a.bits, a.twire, a.tcoef, a.levels, a.nlevels, a.W8, a.rows_per_group, a.flag);
 }
 void launch_wit_rows(const WitRowsArgs& a, size_t groups, hipStream_t s) {
     const unsigned ny = a.n_tiny_chunks + a.n_rgen;

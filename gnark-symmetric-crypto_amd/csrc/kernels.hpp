@@ -89,10 +89,9 @@ void launch_check_count_tables(const uint32_t* prog, const fe* coeff, const uint
 struct WitChainArgs {
     const uint32_t* tiny; const uint32_t* parts; const uint32_t* bits; const uint32_t* twire; const long long* tcoef; const uint32_t* levels; uint32_t nlevels;
     int8_t* W8; size_t rows_per_group; uint32_t* flag;
-    uint32_t max_slots, max_fresh;      // SmallProgram: LDS slots of a level's nBits partial sums (512 B each) and of a level's outputs (64 B each, two copies)
 };
-// one workgroup of 16 waves per proof group
-void launch_wit_chain(const WitChainArgs& a, size_t groups, hipStream_t s);
+// one workgroup of 16 waves per proof group; lds_bytes = 512 * SmallProgram::max_slots
+void launch_wit_chain(const WitChainArgs& a, size_t groups, size_t lds_bytes, hipStream_t s);
 struct WitRowsArgs {
     const uint32_t* rtiny; uint32_t n_rtiny, tiny_per_chunk, n_tiny_chunks; const uint32_t* rgen; uint32_t n_rgen; const uint32_t* rtwire; const long long* rtcoef;
     const int8_t* W8; size_t rows_per_group;

@@ -14,14 +14,14 @@ bool tiny_shape(const Expr& l, const Expr& r, const Expr& o) {
     auto ok = [](const Expr& e) { if (e.size() > 2) return false; for (const Term& t : e) if (t.c >= WS_COEF_TINY || t.c <= -WS_COEF_TINY) return false; return true; };
     return ok(l) && ok(r) && ok(o);
 }
-void put_tiny(std::vector<uint32_t>& out, uint32_t flags, uint32_t where, const Expr& l, const Expr& r, const Expr& o, uint32_t fresh_slot = 0) {
-    uint32_t w[WS_TINY_WORDS] = {flags, where, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, fresh_slot, 0};
+void put_tiny(std::vector<uint32_t>& out, uint32_t flags, uint32_t where, const Expr& l, const Expr& r, const Expr& o) {
+    uint32_t w[WS_TINY_WORDS] = {flags, where, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const Expr* e[3] = {&l, &r, &o};
     for (int s = 0; s < 3; s++) for (size_t k = 0; k < e[s]->size(); k++) { w[2 + 2 * s + k] = (*e[s])[k].wire; w[8 + 2 * s + k] = (uint32_t)(int32_t)(*e[s])[k].c; }
     out.insert(out.end(), w, w + WS_TINY_WORDS);
 }
-void pad_tiny(std::vector<uint32_t>& out, size_t first_item, uint32_t where, uint32_t fresh_slot = 0) {
-    while ((out.size() / WS_TINY_WORDS - first_item) % WS_IB) put_tiny(out, 0u, where, Expr{}, Expr{}, Expr{}, fresh_slot);
+void pad_tiny(std::vector<uint32_t>& out, size_t first_item, uint32_t where) {
+    while ((out.size() / WS_TINY_WORDS - first_item) % WS_IB) put_tiny(out, 0u, where, Expr{}, Expr{}, Expr{});
 }
 // appends the terms of e padded to whole chunks; returns the number of chunks
 uint32_t put_terms(std::vector<uint32_t>& tw, std::vector<int64_t>& tc, const Term* t, size_t n) {
@@ -62,14 +62,9 @@ SmallProgram build_small_program(const SolverProgram& sp, size_t n_wires, size_t
     };
     const double LIM = 4.0e18;      // < 2^62
     std::vector<uint8_t> seen(n_constraints, 0);
-    // where the chain finds a wire: produced by chain level made_in[w] (-1: an input) in LDS slot made_slot[w]; a term of chain level L reads a wire
-    // of level L - 1 from LDS (WS_SRC_FRESH | slot), anything older from memory
-    std::vector<int32_t> made_in(n_wires, -1); std::vector<uint32_t> made_slot(n_wires, 0);
-    auto chain_src = [&](Expr e) { for (Term& t : e) if (made_in[t.wire] >= 0 && (uint32_t)made_in[t.wire] + 1 == P.n_levels) t.wire = WS_SRC_FRESH | made_slot[t.wire]; return e; };
     for (uint32_t l = 0; l < nlev; l++) {
         const size_t tiny0 = P.tiny.size() / WS_TINY_WORDS, part0 = P.parts.size() / 4, bits0 = P.bits.size() / 4;
-        uint32_t slots = 0, fresh = 0;      // LDS slots of this level: nBits partial sums; outputs
-        std::vector<std::pair<uint32_t, uint32_t>> made;      // (wire, slot) of this level's outputs: entered into made_in once the level is complete
+        uint32_t slots = 0;
         for (uint32_t k = lstart[l]; k < lstart[l + 1]; k++) {
             const uint32_t at = ops[k], op = W[at] & 0xFF;
             if (op == OP_R1C) {
@@ -85,8 +80,7 @@ SmallProgram build_small_program(const SolverProgram& sp, size_t n_wires, size_t
                     if (c != 1 && c != -1) return fail("a solved wire with a coefficient other than +-1");
                     if (uw >= n_wires || class_w[uw] > 1) return fail("a solved wire that is not in {-1, 0, 1}");
                     if (!tiny_shape(e[0], e[1], e[2])) return fail("a producing constraint with more than two terms per side");
-                    put_tiny(P.tiny, WS_F_ITEM | (c < 0 ? WS_F_NEG : 0u), uw, chain_src(e[0]), chain_src(e[1]), chain_src(e[2]), fresh);
-                    made.push_back({uw, fresh++});
+                    put_tiny(P.tiny, WS_F_ITEM | (c < 0 ? WS_F_NEG : 0u), uw, e[0], e[1], e[2]);
                     P.n_chain_items++;
                     e[2].push_back(Term{uw, c});      // the full constraint, for the rows
                 } else if (loc != 0) return fail("unknown constraint shape");
@@ -114,32 +108,27 @@ SmallProgram build_small_program(const SolverProgram& sp, size_t n_wires, size_t
                 for (size_t pi = 0; pi < nparts; pi++) {
                     const size_t a = std::min(pi * per, e.size()), b = std::min(a + per, e.size());
                     const uint32_t t0 = (uint32_t)P.twire.size();
-                    const Expr es = chain_src(Expr(e.begin() + a, e.begin() + b));
-                    const uint32_t chunks = put_terms(P.twire, P.tcoef, es.data(), es.size());
+                    const uint32_t chunks = put_terms(P.twire, P.tcoef, e.data() + a, b - a);
                     P.parts.insert(P.parts.end(), {slots++, t0, chunks, 0u});
                 }
                 if (nparts >= (1u << 16) || slots >= (1u << 16)) return fail("an nBits input that is too long");
                 for (uint32_t b0 = 0; b0 < nout; b0 += WS_BITS_PER_ITEM) {
                     const uint32_t nb = std::min(WS_BITS_PER_ITEM, nout - b0);
-                    P.bits.insert(P.bits.end(), {o0 + b0, slot0 | ((uint32_t)nparts << 16), b0 | (nb << 8), fresh + b0});
+                    P.bits.insert(P.bits.end(), {o0 + b0, slot0 | ((uint32_t)nparts << 16), b0 | (nb << 8), 0u});
                 }
-                for (uint32_t b = 0; b < nout; b++) made.push_back({o0 + b, fresh + b});
-                fresh += nout;
                 P.n_nbits++;
             } else return fail("an instruction other than a constraint or an nBits hint");
         }
-        pad_tiny(P.tiny, tiny0, P.scratch_row, fresh);      // (padding items write the slot behind the level's outputs)
+        pad_tiny(P.tiny, tiny0, P.scratch_row);
         const size_t tiny1 = P.tiny.size() / WS_TINY_WORDS, part1 = P.parts.size() / 4, bits1 = P.bits.size() / 4;
         if (tiny1 == tiny0 && part1 == part0) continue;      // a level of checks only: nothing for the chain
-        for (auto& m : made) { made_in[m.first] = (int32_t)P.n_levels; made_slot[m.first] = m.second; }
-        if (fresh + 1 > P.max_fresh) P.max_fresh = fresh + 1;
         P.levels.insert(P.levels.end(), {(uint32_t)tiny0, (uint32_t)tiny1, (uint32_t)part0, (uint32_t)part1, (uint32_t)bits0, (uint32_t)bits1});
         P.n_levels++;
         if (slots > P.max_slots) P.max_slots = slots;
     }
     for (size_t i = 0; i < n_constraints; i++) if (!seen[i]) return fail("a constraint row that no instruction writes");
     pad_tiny(P.rtiny, 0, 0u);
-    if (P.max_slots * 512u + 2u * 64u * P.max_fresh > 65536u) return fail("a level with too many outputs for the workgroup's LDS (" + std::to_string(P.max_slots) + " sums, " + std::to_string(P.max_fresh) + " outputs)");
+    if (P.max_slots * 512u > 60000u) return fail("a level with too many nBits sums");
     // the padding reads of the sums and of the padding items touch wire 0 with coefficient 0: any value will do
     if (P.twire.empty()) { P.twire.assign(WS_CHUNK, 0u); P.tcoef.assign(WS_CHUNK, 0); }
     if (P.rtwire.empty()) { P.rtwire.assign(WS_CHUNK, 0u); P.rtcoef.assign(WS_CHUNK, 0); }

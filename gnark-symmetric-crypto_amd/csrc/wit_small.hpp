@@ -7,9 +7,7 @@
 // expression is a sum below 2^36.  The program below is the same instruction list re-laid for that case:
 //   * wires live in a byte plane W8[group of 64 proofs][wire][64] (0, 1, 0xFF = -1) — a proof group's whole witness is 1.5 MB;
 //   * the CHAIN (k_wit_chain): one workgroup per proof group walks the levels that PRODUCE wires (XOR-style products, nBits
-//     hints) with a workgroup barrier between levels — no kernel boundary, no device-wide barrier, no field arithmetic; a level's
-//     outputs also go to LDS, from where the NEXT level reads them (WS_SRC_FRESH), so that the barrier does not have to wait for the
-//     stores to memory: those are only read two levels later, by which time every wave has seen them acknowledged;
+//     hints) with a workgroup barrier between levels — no kernel boundary, no device-wide barrier, no field arithmetic;
 //   * the ROWS (k_wit_rows): a = L(w), b = R(w), c = O(w) of every constraint, fully parallel, checked (a b == c) and written as
 //     byte planes A8 / B8 / C8 — or as 32-byte Montgomery elements for the few rows that are predicted wide (ChaCha20's 336
 //     add32 sums).
@@ -26,14 +24,13 @@
 namespace gsc {
 
 constexpr uint32_t WS_IB = 8;                 // tiny items per bundle: item lists are padded to a multiple of this
-constexpr uint32_t WS_TINY_WORDS = 16;        // [flags, out | constraint, wire x 6 (L0 L1 R0 R1 O0 O1), coefficient x 6 (int32), chain: LDS slot of the output, 0]
+constexpr uint32_t WS_TINY_WORDS = 16;        // [flags, out | constraint, wire x 6 (L0 L1 R0 R1 O0 O1), coefficient x 6 (int32), 0, 0]
 constexpr uint32_t WS_CHUNK = 8;              // terms per load round of the general sums; term lists are padded to a multiple of this
 constexpr uint32_t WS_PART_CHUNKS = 4;        // a part of an nBits sum: at most 32 terms, one load round
 constexpr uint32_t WS_BITS_PER_ITEM = 9;      // output bits written by one wave of the second phase
 constexpr uint32_t WS_F_ITEM = 1u;            // flags: a real item (0 = padding)
 constexpr uint32_t WS_F_NEG = 1u << 8;        // chain: the solved wire's coefficient is -1
 constexpr int WS_CLS_SHIFT_A = 16, WS_CLS_SHIFT_B = 18, WS_CLS_SHIFT_C = 20;      // rows: 0 = byte plane, 1 = 32-byte element
-constexpr uint32_t WS_SRC_FRESH = 0x80000000u;       // chain terms: the wire was produced by the PREVIOUS chain level — read slot (w & 0x7FFFFFFF) of the workgroup's LDS copy instead of memory
 constexpr int64_t WS_COEF_TINY = (int64_t)1 << 28;      // |coefficient| of a tiny item: sums of two stay in 32 bits
 
 struct SmallProgram {
@@ -45,8 +42,7 @@ struct SmallProgram {
     std::vector<uint32_t> levels; uint32_t n_levels = 0, max_slots = 0;
     std::vector<uint32_t> tiny;               // WS_TINY_WORDS per item: out = +-(L R - O)
     std::vector<uint32_t> parts;              // 4 per part: [LDS slot, first term, chunks, 0]
-    std::vector<uint32_t> bits;               // 4 per item: [first output wire, first slot | parts << 16, first bit | bits << 8, LDS slot of the first output]
-    uint32_t max_fresh = 0;                   // LDS slots (64 bytes each) of a level's outputs: the most any chain level produces, + 1 for the padding items
+    std::vector<uint32_t> bits;               // 4 per item: [first output wire, first slot | parts << 16, first bit | bits << 8, 0]
     std::vector<uint32_t> twire; std::vector<int64_t> tcoef;      // terms of the parts (padded with wire 0 x 0)
     // rows
     std::vector<uint32_t> rtiny;              // WS_TINY_WORDS per constraint, padded to a multiple of WS_IB

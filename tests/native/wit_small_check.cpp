@@ -11,7 +11,6 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
-#include <stdexcept>
 #include <string>
 #include <vector>
 using namespace gsc;
@@ -41,54 +40,39 @@ static uint8_t class_of(const std::vector<int64_t>& vals, const std::vector<uint
 }
 
 struct Emu {
-    const SmallProgram& P; std::vector<int8_t> w8; bool flag = false; std::vector<std::pair<uint32_t, int8_t>> pending;
+    const SmallProgram& P; std::vector<int8_t> w8; bool flag = false;
     std::vector<int64_t> a, b, c; std::vector<uint8_t> abc_plane_ok; uint32_t failed = 0xFFFFFFFFu;
     explicit Emu(const SmallProgram& p) : P(p), w8(p.rows_per_group, 0), a(p.n_constraints), b(p.n_constraints), c(p.n_constraints) {}
-    // a term's wire value: from the byte plane, or (chain terms marked WS_SRC_FRESH) from the LDS copy of the previous chain level's outputs
-    int8_t val(uint32_t w, const std::vector<int8_t>* fresh) const {
-        if (w & WS_SRC_FRESH) { if (!fresh) throw std::runtime_error("a fresh term outside the chain"); return fresh->at(w & ~WS_SRC_FRESH); }
-        return w8[w];
-    }
-    void tiny_sums(const uint32_t* d, int64_t& L, int64_t& R, int64_t& O, const std::vector<int8_t>* fresh = nullptr) const {
-        auto t = [&](int k) { return (int64_t)(int32_t)d[8 + k] * val(d[2 + k], fresh); };
+    void tiny_sums(const uint32_t* d, int64_t& L, int64_t& R, int64_t& O) const {
+        auto t = [&](int k) { return (int64_t)(int32_t)d[8 + k] * w8[d[2 + k]]; };
         L = t(0) + t(1); R = t(2) + t(3); O = t(4) + t(5);
     }
     void chain() {
         std::vector<int64_t> slots(P.max_slots ? P.max_slots : 1);
-        // the device keeps two LDS copies of a level's outputs: level l writes copy l & 1 and reads copy (l - 1) & 1.  Stale slots hold garbage on purpose
-        // (0x55): a term that reads a slot its level did not just write shows up as a wrong wire.
-        std::vector<int8_t> fresh[2] = {std::vector<int8_t>(P.max_fresh, 0x55), std::vector<int8_t>(P.max_fresh, 0x55)};
         for (uint32_t l = 0; l < P.n_levels; l++) {
             const uint32_t* lv = P.levels.data() + 6 * l;
-            const std::vector<int8_t>& in = fresh[(l + 1) & 1]; std::vector<int8_t>& outf = fresh[l & 1];
-            std::fill(outf.begin(), outf.end(), 0x55);
-            // a level's items only read wires of earlier levels: results are collected first, written after (what the barrier guarantees on the device).
-            // Memory holds a level's outputs only from the level AFTER the next one on (the device does not wait for its stores at the barrier): the
-            // plane is updated one level late here, so that a term that should have been marked fresh but was not reads a stale value.
+            // a level's items only read wires of earlier levels: results are collected first, written after (what the barrier guarantees on the device)
             std::vector<std::pair<uint32_t, int8_t>> out;
             for (uint32_t i = lv[0]; i < lv[1]; i++) {
                 const uint32_t* d = P.tiny.data() + (size_t)WS_TINY_WORDS * i;
-                int64_t L, R, O; tiny_sums(d, L, R, O, &in);
+                int64_t L, R, O; tiny_sums(d, L, R, O);
                 int64_t w = L * R - O; if (d[0] & WS_F_NEG) w = -w;
                 if (w < -1 || w > 1) flag = true;
-                out.push_back({d[1], (int8_t)w}); outf.at(d[14]) = (int8_t)w;
+                out.push_back({d[1], (int8_t)w});
             }
             for (uint32_t i = lv[2]; i < lv[3]; i++) {
                 const uint32_t* d = P.parts.data() + 4 * i; int64_t acc = 0;
-                for (uint32_t k = 0; k < d[2] * WS_CHUNK; k++) acc += P.tcoef[d[1] + k] * val(P.twire[d[1] + k], &in);
+                for (uint32_t k = 0; k < d[2] * WS_CHUNK; k++) acc += P.tcoef[d[1] + k] * w8[P.twire[d[1] + k]];
                 slots[d[0]] = acc;
             }
             for (uint32_t i = lv[4]; i < lv[5]; i++) {
                 const uint32_t* d = P.bits.data() + 4 * i; const uint32_t slot0 = d[1] & 0xFFFF, np = d[1] >> 16, sh = d[2] & 0xFF, nb = d[2] >> 8;
                 int64_t s = 0; for (uint32_t k = 0; k < np; k++) s += slots[slot0 + k];
                 if (s < 0) flag = true;
-                for (uint32_t q = 0; q < nb; q++) { const int8_t v = (int8_t)((s >> (sh + q)) & 1); out.push_back({d[0] + q, v}); outf.at(d[3] + q) = v; }
+                for (uint32_t q = 0; q < nb; q++) out.push_back({d[0] + q, (int8_t)((s >> (sh + q)) & 1)});
             }
-            for (auto& o : pending) w8[o.first] = o.second;      // the previous level's outputs reach memory now
-            pending = out;
+            for (auto& o : out) w8[o.first] = o.second;
         }
-        for (auto& o : pending) w8[o.first] = o.second;
-        pending.clear();
     }
     void put(uint32_t flags, uint32_t cidx, int64_t L, int64_t R, int64_t O) {
         if (L * R != O && cidx < failed) failed = cidx;
@@ -138,10 +122,7 @@ int main(int argc, char** argv) {
     const SmallProgram P = build_small_program(sp, nw, nc, coef, coef_ok, cls[0], cls[1], cls[2], cls[3]);
     if (!P.ok) { printf("WIT-SMALL-NO %s\n", P.why.c_str()); return 0; }
     size_t wide = 0; for (size_t i = 0; i < nc; i++) wide += P.cls_a[i] + P.cls_b[i] + P.cls_c[i];
-    size_t fresh_terms = 0, chain_terms = 0;
-    for (size_t i = 0; i < P.tiny.size() / WS_TINY_WORDS; i++) for (int k = 0; k < 6; k++) if ((int32_t)P.tiny[WS_TINY_WORDS * i + 8 + k]) { chain_terms++; fresh_terms += (P.tiny[WS_TINY_WORDS * i + 2 + k] & WS_SRC_FRESH) != 0; }
-    for (size_t i = 0; i < P.twire.size(); i++) if (P.tcoef[i]) { chain_terms++; fresh_terms += (P.twire[i] & WS_SRC_FRESH) != 0; }
-    printf("levels=%u chain_items=%zu nbits=%zu rows_tiny=%u rows_general=%u wide_rows=%zu max_slots=%u max_fresh=%u fresh_terms=%zu/%zu\n", P.n_levels, P.n_chain_items, P.n_nbits, P.n_rtiny, P.n_rgen, wide, P.max_slots, P.max_fresh, fresh_terms, chain_terms);
+    printf("levels=%u chain_items=%zu nbits=%zu rows_tiny=%u rows_general=%u wide_rows=%zu max_slots=%u\n", P.n_levels, P.n_chain_items, P.n_nbits, P.n_rtiny, P.n_rgen, wide, P.max_slots);
     size_t bad = 0;
     for (uint32_t s = 0; s < count; s++) {
         Emu e(P);
