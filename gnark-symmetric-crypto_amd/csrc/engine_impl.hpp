@@ -109,7 +109,7 @@ class AlgorithmImpl {
     void init_small(const SolverProgram& sp);
     std::atomic<uint64_t> small_fallbacks{0};      // chunks that had to be solved again generically (gsc_describe)
     // NTT
-    DevBuf<int32_t> tw_fwd, tw_inv, qr; DevBuf<fe> scale_mid, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n
+    DevBuf<int32_t> tw_fwd, tw_inv, tw_inv_plain, qr; DevBuf<fe> scale_mid, scale_mid_plain, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n
     // MSM sets
     MsmSet<G1Aff> mA, mB1, mK, mZ, mZfew, mPed, mPedSigma; MsmSet<G2Aff> mB2;     // mPed*: Pedersen commitment bases (AES-V2)
     // Evaluation-form quotient (k_quot_bases.hip, cfg.quotient_eval): mZ then holds the bases V_i (scalars: d on the zeta-coset, launch_compute_d)

@@ -314,8 +314,8 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     }
     // 2. quotient polynomial.  Coefficient form: h overwrites A, canonical, bit-reversed order (six transforms).  Evaluation form (batch calls,
     // k_quot_bases.hip): d = A B on the zeta-coset overwrites A, natural order (four transforms); c stays where the solver wrote it.
-    NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, trace ? ln.d_clk.p + 4 : nullptr};
-    const NttNarrow planes{{ln.d_A8.p, ln.d_B8.p, ln.d_C8.p}, n_constraints};
+    NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, trace ? ln.d_clk.p + 4 : nullptr, tw_inv_plain.p, scale_mid_plain.p};
+    const NttNarrow planes{{ln.d_A8.p, ln.d_B8.p, ln.d_C8.p}, n_constraints, cfg.ntt_plain};
     const NttNarrow* narrow = small_call ? &planes : nullptr;      // a, b (and c) of this chunk are byte planes
     HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
     const bool few_call = ln.n_real <= (size_t)cfg.few_max && cfg.few_path;

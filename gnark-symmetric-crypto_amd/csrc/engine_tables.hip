@@ -348,10 +348,10 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
         DevBuf<uint8_t> d_be(sizeof be); d_be.upload(be, sizeof be, stream);
         dom.alloc(6);
         launch_fr_from_be(d_be.p, dom.p, 5, stream);
-        tw_fwd.alloc(domain_n / 2 * 12); tw_inv.alloc(domain_n / 2 * 12); scale_mid.alloc(domain_n); scale_out.alloc(domain_n); qr.alloc((2 * NTT_QMAX + 1) * 12);
+        tw_fwd.alloc(domain_n / 2 * 12); tw_inv.alloc(domain_n / 2 * 12); scale_mid.alloc(domain_n); scale_mid_plain.alloc(domain_n); tw_inv_plain.alloc(domain_n / 2 * 12); scale_out.alloc(domain_n); qr.alloc((2 * NTT_QMAX + 1) * 12);
         DevBuf<uint32_t> d_flag(1); uint32_t flag = 0;
         HIP_CHECK(hipMemsetAsync(d_flag.p, 0, 4, stream));
-        launch_ntt_constants(dom.p, dom.p + 1, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, d_flag.p, stream);
+        launch_ntt_constants(dom.p, dom.p + 1, dom.p + 4, L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, d_flag.p, tw_inv_plain.p, scale_mid_plain.p, stream);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

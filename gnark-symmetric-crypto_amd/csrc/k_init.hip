@@ -195,7 +195,7 @@ __device__ __forceinline__ fe fr_root_2_28() {
     return Fr::to_mont(c);
 }
 __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* n_inv, int L,
-                                int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag) {
+                                int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag, int32_t* tw_inv_plain, fe* scale_mid_plain) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 1u << L;
     if (i <= 2 * NTT_QMAX) {      // q*r, q = i - NTT_QMAX, as tight limbs with a signed top limb: the NTT kernels' range reduction subtracts these
@@ -211,6 +211,8 @@ __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* 
         const fe9 f = Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(fr_pow_u32(*omega, i)))));
         const fe9 b = Fr29::freeze(Fr29::to_mont(Fr29::unpack(Fr::from_mont(fr_pow_u32(*omega_inv, i)))));
         for (int k = 0; k < 12; k++) { tw_fwd[12 * (size_t)i + k] = k < 9 ? f.l[k] : 0; tw_inv[12 * (size_t)i + k] = k < 9 ? b.l[k] : 0; }
+        const fe9 bp = Fr29::unpack(Fr::from_mont(fr_pow_u32(*omega_inv, i)));      // the same power as a canonical integer (tight limbs)
+        for (int k = 0; k < 12; k++) tw_inv_plain[12 * (size_t)i + k] = k < 9 ? bp.l[k] : 0;
     }
     fe zeta = fr_root_2_28();                       // -> the primitive 2n-th root: 27 - L squarings
     for (int t = 0; t < 27 - L; t++) zeta = Fr::sqr(zeta);
@@ -219,7 +221,10 @@ __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* 
     {
         fe9 c; for (int k = 0; k < 9; k++) c.l[k] = Fr29Q::FROM_R256(k);
         const fe9 sm = Fr29::to_mont(Fr29::unpack(Fr::from_mont(Fr::mul(*n_inv, fr_pow_u32(zeta, br)))));
-        scale_mid[i] = Fr29::pack(Fr29::freeze(Fr29::mul(sm, c)));
+        const fe9 smc = Fr29::freeze(Fr29::mul(sm, c));
+        scale_mid[i] = Fr29::pack(smc);
+        fe one256; for (int k = 0; k < 8; k++) one256.l[k] = FrParams::one(k);      // 2^256 mod r
+        scale_mid_plain[i] = Fr29::pack(Fr29::freeze(Fr29::mul(smc, Fr29::to_mont(Fr29::unpack(one256)))));      // scale_mid * 2^256
     }
     const fe half = Fr::inv(Fr::from_u32(2));
     scale_out[i] = Fr::from_mont(Fr::mul(Fr::mul(*n_inv, half), fr_pow_u32(zeta_inv, br)));
@@ -306,11 +311,11 @@ void launch_build_subset_g2(const G2Aff* bases, size_t ngroups, G2Aff* table, G2
                                     reinterpret_cast<const Aff<Fp2>*>(bases), ngroups, reinterpret_cast<fe*>(table), reinterpret_cast<fe*>(scratch), ok);
 }
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* n_inv, int L,
-                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag, hipStream_t s) {
+                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag, int32_t* tw_inv_plain, fe* scale_mid_plain, hipStream_t s) {
     size_t n = (size_t)1 << L;
     if (n < 2 * NTT_QMAX + 1) n = 2 * NTT_QMAX + 1;
     hipLaunchKernelGGL(k_ntt_constants, dim3(blocks_for(n, 64)), dim3(64), 0, s, omega, omega_inv, n_inv, L,
-                       tw_fwd, tw_inv, scale_mid, scale_out, half_c, qr, flag);
+                       tw_fwd, tw_inv, scale_mid, scale_out, half_c, qr, flag, tw_inv_plain, scale_mid_plain);
 }
 
 }  // namespace gsc

@@ -218,6 +218,15 @@ __device__ __forceinline__ fe9 narrow9(int t) {
     return r;
 }
 
+// a small integer as limbs; w * k for a canonical twiddle w and |k| <= 4 (|limb| < 2^31: norm() takes it from there)
+__device__ __forceinline__ fe9 small9(int k) { fe9 r = F::zero(); r.l[0] = k; return r; }
+__device__ __forceinline__ fe9 scale9(const fe9& w, int k) {
+    fe9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = w.l[i] * k;
+    return r;
+}
+
 struct ClkStamp {      // diagnostics: the shader clock a kernel runs at = (shader-clock ticks) / (100 MHz ticks) over the life of one workgroup in the middle of the grid
     unsigned long long* p;
     __device__ __forceinline__ ClkStamp(unsigned long long* clk, int slot) : p(nullptr) {
@@ -239,6 +248,46 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
     const ClkStamp cs(pl.clk, 0);
     Tile t{smem, G * P};
     const int8_t* plane = blockIdx.z == 0 ? nr.plane[0] : blockIdx.z == 1 ? nr.plane[1] : nr.plane[2];
+    if (plane && nr.plain) {
+        // The plane's small integers themselves, not their Montgomery images (the next kernel's scale table makes up for it).  This thread's four
+        // elements u4 + k G/4 are exactly the ones its first two stages couple, so those run in registers: on ternary inputs (every row of `a`, all but
+        // the 336 add32 rows of `b`) three of the four products are twiddles scaled by integers in [-4, 4].
+        const int8_t* pp = plane + ((q0 + q) >> 6) * nr.crows * 64 + ((q0 + q) & 63);
+        const uint32_t he2 = G / 4, e0 = u4, e1 = u4 + he2, e2 = u4 + 2 * he2, e3 = u4 + 3 * he2;
+        const size_t i0 = ((size_t)e0 << Llo) + g, i1 = ((size_t)e1 << Llo) + g, i2 = ((size_t)e2 << Llo) + g, i3 = ((size_t)e3 << Llo) + g;
+        const int t0 = i0 < m ? (int)pp[i0 * 64] : 0, t1 = i1 < m ? (int)pp[i1 * 64] : 0, t2 = i2 < m ? (int)pp[i2 * 64] : 0, t3 = i3 < m ? (int)pp[i3 * 64] : 0;
+        const uint32_t hg1 = 1u << (L - 1), hg2 = hg1 >> 1;
+        const uint32_t g0 = (uint32_t)i0, g1 = (uint32_t)i1, g2 = (uint32_t)i2;
+        const uint32_t exA = g0 & (hg1 - 1), exB = g1 & (hg1 - 1), exC = (g0 & (hg2 - 1)) << 1, exD = (g2 & (hg2 - 1)) << 1;
+        const bool small = t0 != (int)WS_PLANE_WIDE && t1 != (int)WS_PLANE_WIDE && t2 != (int)WS_PLANE_WIDE && t3 != (int)WS_PLANE_WIDE;
+        if (__all(small)) {
+            const fe9 wA = load_tw(pl.tw_inv_plain, exA), wB = load_tw(pl.tw_inv_plain, exB), wC = load_tw(pl.tw_inv_plain, exC);
+            const int a0 = t0 + t2, a1 = t1 + t3;
+            const fe9 A2 = scale9(wA, t0 - t2), A3 = scale9(wB, t1 - t3);
+            t.put(e0, q, small9(a0 + a1));
+            t.put(e2, q, F::norm(F::add(A2, A3)));
+            t.put(e1, q, F::norm(scale9(wC, a0 - a1)));
+            t.put(e3, q, F::mul(F::norm(F::sub(A2, A3)), load_tw(pl.tw_inv, exD)));
+        } else {
+            fe9 c32 = F::zero(); c32.l[0] = 32;      // x * 32 / 2^261 = x / 2^256: a 32-byte row out of the solver's Montgomery domain
+            auto val = [&](int tv, size_t idx) { return tv == (int)WS_PLANE_WIDE ? F::mul(F::unpack(ld_stream(vec + idx * batch + q0 + q)), c32) : small9(tv); };
+            const fe9 x0 = val(t0, i0), x1 = val(t1, i1), x2 = val(t2, i2), x3 = val(t3, i3);
+            const fe9 a0 = F::add(x0, x2), a1 = F::add(x1, x3);
+            const fe9 a2 = mulw<false>(F::sub(x0, x2), pl.tw_inv, exA, pl.qr), a3 = mulw<false>(F::sub(x1, x3), pl.tw_inv, exB, pl.qr);
+            t.put(e0, q, F::norm(F::add(a0, a1)));
+            t.put(e2, q, F::norm(F::add(a2, a3)));
+            t.put(e1, q, mulw<false>(F::sub(a0, a1), pl.tw_inv, exC, pl.qr));
+            t.put(e3, q, mulw<false>(F::sub(a2, a3), pl.tw_inv, exD, pl.qr));
+        }
+        __syncthreads();
+        dif_run<true>(t, u4, q, 2, Lhi, 2, L, Llo, g, pl, G);
+        for (uint32_t e = u4; e < G; e += G / 4) {
+            const size_t idx = ((size_t)e << Llo) + g;
+            store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
+        }
+        cs.end();
+        return;
+    }
     if (plane) {      // (wave-uniform) the small-integer witness path left this vector as a byte plane; the few wide rows are 32-byte elements in `vec`
         const int8_t* pp = plane + ((q0 + q) >> 6) * nr.crows * 64 + ((q0 + q) & 63);
         for (uint32_t e = u4; e < G; e += G / 4) {
@@ -436,9 +485,12 @@ hipError_t launch_quotient(const NttPlan& p, fe* a, fe* b, fe* c, size_t m, size
     opt_in(eval == 2 ? reinterpret_cast<const void*>(k_ntt_pointwise_strided<2>) : eval ? reinterpret_cast<const void*>(k_ntt_pointwise_strided<1>) : reinterpret_cast<const void*>(k_ntt_pointwise_strided<0>), lds_s);
     opt_in(reinterpret_cast<const void*>(k_ntt_mid_contig), lds_c); opt_in(reinterpret_cast<const void*>(k_ntt_final_contig), lds_c);
     if (e != hipSuccess) return e;
-    const NttNarrow nr = narrow ? *narrow : NttNarrow{{nullptr, nullptr, nullptr}, 0};
+    NttNarrow nr = narrow ? *narrow : NttNarrow{{nullptr, nullptr, nullptr}, 0, 0};
+    // plain-integer inputs: evaluation form only (the coefficient form's last kernel prices c in the solver's domain), both vectors as planes, tables present
+    nr.plain = nr.plain && eval && nr.plane[0] && nr.plane[1] && p.tw_inv_plain && p.scale_mid_plain && Lhi >= 3 ? 1 : 0;
+    NttPlan p2 = p; if (nr.plain) p2.scale_mid = p.scale_mid_plain;
     hipLaunchKernelGGL(k_ntt_dif_strided, dim3(Cn, pb, eval ? 2 : 3), dim3(G / 4 * P), lds_s, s, p, a, b, c, m, batch, nr);
-    hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 2), dim3(Cn / 4 * P), lds_c, s, p, a, b, c, batch);
+    hipLaunchKernelGGL(k_ntt_mid_contig, dim3(G, pb, 2), dim3(Cn / 4 * P), lds_c, s, p2, a, b, c, batch);
     if (eval == 2) { hipLaunchKernelGGL(k_ntt_pointwise_strided<2>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch, qd); return hipGetLastError(); }
     if (eval) { hipLaunchKernelGGL(k_ntt_pointwise_strided<1>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch, qd); return hipGetLastError(); }
     hipLaunchKernelGGL(k_ntt_pointwise_strided<0>, dim3(Cn, pb, 1), dim3(G / 4 * P), lds_s, s, p, a, b, batch, qd);

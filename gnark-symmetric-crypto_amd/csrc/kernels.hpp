@@ -29,8 +29,10 @@ void launch_fr_inverse(const fe* in, fe* out, size_t n, hipStream_t s);
 // scale_mid[pos] = n^-1 * zeta^bitrev(pos) (times the factor that moves the solver's 2^256-domain values into the NTT kernels' 2^261
 // domain); scale_out[pos] = (2n)^-1 * zeta^-bitrev(pos) and half_c = 16 / n as plain integers, so that the Montgomery products with
 // them leave the result in canonical form.  *flag |= 1 if omega is not that root's 2^(28-L)-th power (not a gnark domain).
+// tw_inv_plain[i] = w^-i as a canonical integer in limbs (same 12-word entries); scale_mid_plain[pos] = scale_mid[pos] * 2^256: for inputs that are plain
+// small integers instead of 2^256-domain images (NttNarrow::plain).
 void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* n_inv, int L,
-                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag, hipStream_t s);
+                          int32_t* tw_fwd, int32_t* tw_inv, fe* scale_mid, fe* scale_out, fe* half_c, int32_t* qr, uint32_t* flag, int32_t* tw_inv_plain, fe* scale_mid_plain, hipStream_t s);
 
 // TEST HOOK: radix-2^29 field self-test.  field 0 = Fp, 1 = Fr; a, b, out: n canonical 32-byte little-endian values (device memory).
 void launch_field_ops(int field, int op, const fe* a, const fe* b, fe* out, size_t n, int chain, hipStream_t s);
@@ -117,9 +119,13 @@ void launch_classify_wires(const fe* W, size_t n_wires, size_t batch, const uint
 // Byte planes of the small-integer witness path as inputs of the first transform kernel: plane[k] (or nullptr) for vector k = a, b, c;
 // an entry 0, 1, -1 stands for that value (its 2^256 Montgomery image), WS_PLANE_WIDE says the row's 32-byte element is in the vector itself.
 constexpr int8_t WS_PLANE_WIDE = -128;
-struct NttNarrow { const int8_t* plane[3]; size_t crows; };      // plane[(group * crows + row) * 64 + lane]
+// plain: the first transform works on the byte planes' small integers THEMSELVES (not on their 2^256 Montgomery images): the first two butterfly stages of
+// ternary inputs are then scalings of twiddles by integers in [-4, 4] instead of field products; the second kernel's scale table absorbs the change of
+// domain (NttPlan::scale_mid_plain).  Evaluation-form launches only (launch_compute_d*).
+struct NttNarrow { const int8_t* plane[3]; size_t crows; int plain = 0; };      // plane[(group * crows + row) * 64 + lane]
 struct NttPlan { int L; const int32_t* tw_fwd; const int32_t* tw_inv; const fe* scale_mid; const fe* scale_out; const fe* half_c; const int32_t* qr;
-                 unsigned long long* clk = nullptr; };      // clk (diagnostics): kernel k's middle workgroup stamps {100 MHz clock, shader clock} at its start and end into clk[4 k ..]   // tw_*, qr: 12 int32 per entry (limbs)
+                 unsigned long long* clk = nullptr;
+                 const int32_t* tw_inv_plain = nullptr; const fe* scale_mid_plain = nullptr; };      // (NttNarrow::plain) tw_inv as canonical integers; scale_mid x 2^256      // clk (diagnostics): kernel k's middle workgroup stamps {100 MHz clock, shader clock} at its start and end into clk[4 k ..]   // tw_*, qr: 12 int32 per entry (limbs)
 constexpr int NTT_QMAX = 512;      // qr[q + NTT_QMAX] = q*r as limbs, q = -NTT_QMAX .. NTT_QMAX (range reduction by the top limb)
 // a,b,c: [n][batch] Montgomery, first m rows valid (rows >= m are treated as zero and need not be initialised), c = a*b row by row
 // (a satisfied constraint system; otherwise the result is not gnark's).  On return `a` holds h in canonical form:

@@ -251,6 +251,8 @@ def test_small_integer_witness_path_is_taken_checked_and_abandoned_when_a_predic
     assert "witness=small-integer" in wrong["DESCRIBE"] and "fallbacks 0)" not in wrong["DESCRIBE"], wrong["DESCRIBE"]
     assert wrong["DIGEST"] == small["DIGEST"]
     assert _child({})["DIGEST"] == small["DIGEST"]      # (and the default configuration, latency path on)
+    # GSC_NTT_PLAIN=0: the first transform kernel takes the planes' Montgomery images (like the generic path) instead of the small integers themselves
+    assert _child({"GSC_NTT_PLAIN": "0", "GSC_FEW_PATH": "0"})["DIGEST"] == small["DIGEST"]
     # calls on the latency path: the same kernels (one workgroup walks the levels) or, switched off, the resident lanes-are-terms solver
     few = _child({"TEST_STATEMENTS": "5", "GSC_MAX_BATCH": "64"}); few_res = _child({"TEST_STATEMENTS": "5", "GSC_MAX_BATCH": "64", "GSC_SMALL_WITNESS_FEW": "0"})
     assert few["DIGEST"] == few_res["DIGEST"] == _child({"TEST_STATEMENTS": "5", "GSC_MAX_BATCH": "64", "GSC_FEW_PATH": "0", "GSC_SMALL_WITNESS": "0"})["DIGEST"]
