@@ -54,9 +54,11 @@ __device__ __forceinline__ fe9 reduce_top(const fe9& x, const int32_t* qr) {
     r.l[4] = t.l[4] - b.x; r.l[5] = t.l[5] - b.y; r.l[6] = t.l[6] - b.z; r.l[7] = t.l[7] - b.w; r.l[8] = t.l[8] - c.x;
     return r;      // signed-tight
 }
-// memory image between kernels: non-negative, tight, < 2^256 (not necessarily < r)
+// memory image between kernels: non-negative, tight, < 2^256 (not necessarily < r).  REDUCED: x is known to lie in (-1.001 r, 2.001 r) already (signed-tight limbs: the
+// outputs of a reducing butterfly round), so the estimate-and-subtract step is skipped.
+template <bool REDUCED = false>
 __device__ __forceinline__ void store_lazy(fe* p, const fe9& x, const int32_t* qr) {
-    fe9 t = F::norm(reduce_top(x, qr));
+    fe9 t = REDUCED ? F::norm(x) : F::norm(reduce_top(x, qr));
     const bool lo = t.l[8] < 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) t.l[i] += lo ? F::PK(1, i) : 0;     // + 2r: (-1.001 r, 2.001 r) -> [0, 2.001 r)
@@ -147,8 +149,9 @@ __device__ __forceinline__ void dif_round4(const Tile& t, uint32_t u4, uint32_t 
 // DIF stages s0 .. s1-1 on a tile of E elements.  `d` = doublings of the sum path since its last range reduction (on entry: d0 <= 1);
 // a round that would leave more than four of them reduces instead (values stay below 32 r, products need < 111 r).
 template <bool STRIDED>
-__device__ __forceinline__ void dif_run(const Tile& t, uint32_t u4, uint32_t q, int s0, int s1, int d0, int L, int Llo, uint32_t tile_id, const NttPlan& pl, uint32_t E) {
-    int s = s0, d = d0;
+// Returns true when the last round reduced every entry it wrote (values in (-1.001 r, 2.001 r)): the caller's store can then skip its own range reduction.
+__device__ __forceinline__ bool dif_run(const Tile& t, uint32_t u4, uint32_t q, int s0, int s1, int d0, int L, int Llo, uint32_t tile_id, const NttPlan& pl, uint32_t E) {
+    int s = s0, d = d0; bool last_reduced = false;
     auto half_of = [&](int st) { const uint32_t hg = 1u << (L - 1 - st); return STRIDED ? hg >> Llo : hg; };
     if ((s1 - s0) & 1) {
         dif_stage<STRIDED, false>(t, u4, q, half_of(s), s, L, Llo, tile_id, pl);
@@ -157,10 +160,11 @@ __device__ __forceinline__ void dif_run(const Tile& t, uint32_t u4, uint32_t q, 
         s++; d++;
     }
     for (; s < s1; s += 2) {
-        if (d >= 1) { dif_round4<STRIDED, true>(t, u4, q, half_of(s + 1), s, L, Llo, tile_id, pl); d = 0; }
-        else { dif_round4<STRIDED, false>(t, u4, q, half_of(s + 1), s, L, Llo, tile_id, pl); d += 2; }
+        if (d >= 1) { dif_round4<STRIDED, true>(t, u4, q, half_of(s + 1), s, L, Llo, tile_id, pl); d = 0; last_reduced = true; }
+        else { dif_round4<STRIDED, false>(t, u4, q, half_of(s + 1), s, L, Llo, tile_id, pl); d += 2; last_reduced = false; }
         __syncthreads();
     }
+    return last_reduced;
 }
 
 // DIT.  Tile convention: entries may carry one lazy addition (|limb| < 2^30); u is carried when it is read, v goes straight into
@@ -280,10 +284,10 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
             t.put(e3, q, mulw<false>(F::sub(a2, a3), pl.tw_inv, exD, pl.qr));
         }
         __syncthreads();
-        dif_run<true>(t, u4, q, 2, Lhi, 2, L, Llo, g, pl, G);
+        const bool red = dif_run<true>(t, u4, q, 2, Lhi, 2, L, Llo, g, pl, G);      // (wave-uniform: it depends on the stage count only)
         for (uint32_t e = u4; e < G; e += G / 4) {
             const size_t idx = ((size_t)e << Llo) + g;
-            store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
+            if (red) store_lazy<true>(vec + idx * batch + q0 + q, t.get(e, q), pl.qr); else store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
         }
         cs.end();
         return;
@@ -306,10 +310,10 @@ __global__ __launch_bounds__(512) void k_ntt_dif_strided(NttPlan pl, fe* v0, fe*
         }
     }
     __syncthreads();
-    dif_run<true>(t, u4, q, 0, Lhi, 0, L, Llo, g, pl, G);
+    const bool red = dif_run<true>(t, u4, q, 0, Lhi, 0, L, Llo, g, pl, G);
     for (uint32_t e = u4; e < G; e += G / 4) {
         const size_t idx = ((size_t)e << Llo) + g;
-        store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
+        if (red) store_lazy<true>(vec + idx * batch + q0 + q, t.get(e, q), pl.qr); else store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
     cs.end();
 }

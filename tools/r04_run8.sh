@@ -3,7 +3,7 @@
 set -o pipefail
 export PYTHONUNBUFFERED=1
 O=gpurun_out/r04i; mkdir -p $O
-python -m pytest tests -m gpu -x -q -k "timed_configuration or kat or small_integer" > $O/pytest_sel.txt 2>&1; rc=$?; tail -5 $O/pytest_sel.txt; [ $rc -eq 0 ] || exit $rc
+python -m pytest tests -m gpu -x -q -k "timed_configuration or kat or small_integer or compute_h or compute_d or aes" > $O/pytest_sel.txt 2>&1; rc=$?; tail -5 $O/pytest_sel.txt; [ $rc -eq 0 ] || exit $rc
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats -d $O/stats -o run --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --verify 0 > $O/stats_bench.json 2> $O/stats.err && echo "stats ok"
 rm -rf $O/stats/*kernel_trace.csv 2>/dev/null
