@@ -194,10 +194,20 @@ __device__ __forceinline__ void dit_round4(const Tile& t, uint32_t u4, uint32_t 
     t.put(e0, q, F::add(a0, w2)); t.put(e2, q, F::sub(a0, w2));
     t.put(e1, q, F::add(a1, w3)); t.put(e3, q, F::sub(a1, w3));
 }
-template <bool STRIDED>
+// SINGLE_LAST: an odd number of stages runs its left-over single stage at the end instead of at the start
+template <bool STRIDED, bool SINGLE_LAST = false>
 __device__ __forceinline__ void dit_run(const Tile& t, uint32_t u4, uint32_t q, int s0, int s1, int L, int Llo, uint32_t tile_id, const NttPlan& pl, uint32_t E) {
     int s = s0;
     auto half_of = [&](int st) { return STRIDED ? 1u << (st - Llo) : 1u << st; };
+    if (SINGLE_LAST) {
+        for (; s + 1 < s1; s += 2) { dit_round4<STRIDED>(t, u4, q, half_of(s), s, L, Llo, tile_id, pl); __syncthreads(); }
+        if (s < s1) {
+            dit_stage<STRIDED>(t, u4, q, half_of(s), s, L, Llo, tile_id, pl);
+            dit_stage<STRIDED>(t, u4 + E / 4, q, half_of(s), s, L, Llo, tile_id, pl);
+            __syncthreads();
+        }
+        return;
+    }
     if ((s1 - s0) & 1) {
         dit_stage<STRIDED>(t, u4, q, half_of(s), s, L, Llo, tile_id, pl);
         dit_stage<STRIDED>(t, u4 + E / 4, q, half_of(s), s, L, Llo, tile_id, pl);
@@ -333,13 +343,27 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
         t.put(e, q, F::unpack(ld_stream(vec + idx * batch + q0 + q)));
     }
     __syncthreads();
-    dif_run<false>(t, u4, q, Lhi, L, 0, L, Llo, b, pl, Cn);
-    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
-        const size_t idx = ((size_t)b << Llo) + e;
-        t.put(e, q, F::mul(t.get(e, q), F::load(pl.scale_mid + idx)));
+    dif_run<false>(t, u4, q, Lhi, L - 2, 0, L, Llo, b, pl, Cn);      // all but the last two inverse stages
+    {
+        // The last two inverse stages, the scaling and the first two forward stages couple the SAME four consecutive elements 4 u4 .. 4 u4 + 3: they run in
+        // registers — two LDS round trips, two barriers and the range reductions between them are gone, and the twiddles that are 1 for every thread
+        // (exponent 0: the even pairs of stage L-2 and of stage 1) cost no product.  Same values mod r as the stage-by-stage form.
+        const uint32_t e0 = 4 * u4;
+        const size_t idx0 = ((size_t)b << Llo) + e0;
+        const uint32_t exQ = 1u << (L - 2);                              // the primitive fourth root's exponent: the odd pairs of stage L-2 (inverse) and of stage 1 (forward)
+        const fe9 x0 = t.get(e0, q), x1 = t.get(e0 + 1, q), x2 = t.get(e0 + 2, q), x3 = t.get(e0 + 3, q);
+        const fe9 a0 = F::add(x0, x2), a1 = F::add(x1, x3);
+        const fe9 a2 = F::sub(x0, x2), a3 = mulw<false>(F::sub(x1, x3), pl.tw_inv, exQ, pl.qr);
+        // (products contract whatever the range: at most four unreduced doublings here, < 32 r against the 111 r a product takes)
+        const fe9 z0 = F::mul(F::norm(F::add(a0, a1)), F::load(pl.scale_mid + idx0)), z1 = F::mul(F::norm(F::sub(a0, a1)), F::load(pl.scale_mid + idx0 + 1));
+        const fe9 z2 = F::mul(F::norm(F::add(a2, a3)), F::load(pl.scale_mid + idx0 + 2)), z3 = F::mul(F::norm(F::sub(a2, a3)), F::load(pl.scale_mid + idx0 + 3));
+        const fe9 c0 = F::norm(F::add(z0, z1)), c1 = F::sub(z0, z1);     // forward stage 0: pairs (e0, e0 + 1), (e0 + 2, e0 + 3), every twiddle 1
+        const fe9 w2 = F::norm(F::add(z2, z3)), w3 = mulw<false>(F::sub(z2, z3), pl.tw_fwd, exQ, pl.qr);      // forward stage 1: pairs (e0, e0 + 2) twiddle 1, (e0 + 1, e0 + 3) the fourth root
+        t.put(e0, q, F::add(c0, w2)); t.put(e0 + 2, q, F::sub(c0, w2));
+        t.put(e0 + 1, q, F::add(c1, w3)); t.put(e0 + 3, q, F::sub(c1, w3));
     }
     __syncthreads();
-    dit_run<false>(t, u4, q, 0, Llo, L, Llo, b, pl, Cn);
+    dit_run<false, true>(t, u4, q, 2, Llo, L, Llo, b, pl, Cn);
     for (uint32_t e = u4; e < Cn; e += Cn / 4) {
         const size_t idx = ((size_t)b << Llo) + e;
         store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
