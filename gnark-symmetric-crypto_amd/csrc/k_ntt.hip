@@ -412,12 +412,12 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
         __syncthreads();
     }
     if (EVAL == 1) {
-        auto put_d = [&](uint32_t e, const fe9& v) { st_stream(va + (((size_t)e << Llo) + g) * batch + q0 + q, F::pack(F::freeze(v))); };
+        auto put_d = [&](uint32_t e, const fe9& v) { st_stream(va + (((size_t)e << Llo) + g) * batch + q0 + q, F::pack(F::freeze_near(v))); };      // a*b in (-1.4 r, 2.4 r)
         put_d(u4, lo0); put_d(u4 + G / 2, hi0); put_d(u4 + G / 4, lo1); put_d(u4 + G / 4 + G / 2, hi1);
         return;
     }
     if (EVAL == 2) {
-        fe s[4] = {F::pack(F::freeze(lo0)), F::pack(F::freeze(lo1)), F::pack(F::freeze(hi0)), F::pack(F::freeze(hi1))};      // elements u4 + {0, 1, 2, 3} * G/4
+        fe s[4] = {F::pack(F::freeze_near(lo0)), F::pack(F::freeze_near(lo1)), F::pack(F::freeze_near(hi0)), F::pack(F::freeze_near(hi1))};      // elements u4 + {0, 1, 2, 3} * G/4; a*b in (-1.4 r, 2.4 r)
         const size_t mq = (size_t)g * (G / 4) + u4, o = mq >> 1, half = mq & 1, noct = ((size_t)1 << L) / 8, p = q0 + q;
         const uint32_t c = (uint32_t)qd.c, cmask = (1u << c) - 1, D = 1u << (c - 1);
         uint32_t carry = 0;
