@@ -133,7 +133,7 @@ class AlgorithmImpl {
         // pinned staging: inputs / randomness / masks up, proof coordinates / flags / status / commitment points and the small result words down
         PinnedBuf<uint8_t> h_in, h_rs, h_mask, h_out, h_flags, h_cpts; PinnedBuf<uint32_t> h_status; PinnedBuf<GlvSplit> h_glv; PinnedBuf<unsigned long long> h_words;
         KernelStat stat;                // of the chunk this lane proved last
-        DevBuf<unsigned long long> d_clk;      // clock stamps of the Z kernel (MsmWinArgs::clk); [4 ..16): of the three transform kernels (GSC_TRACE_HOST)
+        DevBuf<unsigned long long> d_clk;      // clock stamps: [0, 32) eight waves of the Z kernel (MsmWinArgs::clk); [32, 44) the three transform kernels (GSC_TRACE_HOST)
         size_t n_real = 0;              // statements of the chunk being proved (the batch is padded to a multiple of 64)
         size_t cap = 0;
         DevBuf<uint8_t> d_inputs, d_rs, d_out, d_flags, d_mask_in, d_cpts; DevBuf<uint32_t> d_status, d_fsync; DevBuf<GlvSplit> d_glv;

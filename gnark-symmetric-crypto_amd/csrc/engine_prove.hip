@@ -314,7 +314,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     }
     // 2. quotient polynomial.  Coefficient form: h overwrites A, canonical, bit-reversed order (six transforms).  Evaluation form (batch calls,
     // k_quot_bases.hip): d = A B on the zeta-coset overwrites A, natural order (four transforms); c stays where the solver wrote it.
-    NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, trace ? ln.d_clk.p + 4 : nullptr, tw_inv_plain.p, scale_mid_plain.p};
+    NttPlan plan{L, tw_fwd.p, tw_inv.p, scale_mid.p, scale_out.p, dom.p + 5, qr.p, trace ? ln.d_clk.p + 32 : nullptr, tw_inv_plain.p, scale_mid_plain.p};
     const NttNarrow planes{{ln.d_A8.p, ln.d_B8.p, ln.d_C8.p}, n_constraints, cfg.ntt_plain};
     const NttNarrow* narrow = small_call ? &planes : nullptr;      // a, b (and c) of this chunk are byte planes
     HIP_CHECK(hipGetLastError());      // witness launches (launch-configuration errors are not sticky: check each group)
@@ -384,7 +384,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     if (small_call) HIP_CHECK(hipMemcpyAsync(&h_wsflag, ln.d_wsflag.p, 4, hipMemcpyDeviceToHost, ln.stream));
     wipe_secrets(ln, B, small_call);      // behind the last kernel of the chunk, inside the wait below
     unsigned long long* const h_clk = hw + 2;
-    if (!latency_call) HIP_CHECK(hipMemcpyAsync(h_clk, ln.d_clk.p, trace ? 128 : 32, hipMemcpyDeviceToHost, ln.stream));
+    if (!latency_call) { HIP_CHECK(hipMemcpyAsync(h_clk, ln.d_clk.p, (trace ? 44 : 32) * 8, hipMemcpyDeviceToHost, ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_clk.p, 0, 32 * 8, ln.stream)); }
     const auto tc1 = std::chrono::steady_clock::now();
     HIP_CHECK(hipStreamSynchronize(ln.stream));
     const auto tc2 = std::chrono::steady_clock::now();
@@ -407,8 +407,10 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         st.name = latency_call ? (small_call ? "k_wit_chain + k_wit_rows" : few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
         st.ms = ln.msm_z_kernel_ms; st.statements = n; st.columns = B; st.nbases = mZ.nwide; st.nwin = mZ.nwin;
         for (int k = 0; k < 4; k++) st.stage_ms[k] = ln.stage_ms[k];
-        // shader clock of the Z launch: (shader-clock ticks) / (100 MHz ticks) of one wave's life in the middle of the grid
-        st.clock_mhz = (!latency_call && h_clk[2] > h_clk[0] && h_clk[3] > h_clk[1]) ? (float)(100.0 * (double)(h_clk[3] - h_clk[1]) / (double)(h_clk[2] - h_clk[0])) : 0.f;
+        // shader clock of the Z launch: (shader-clock ticks) / (100 MHz ticks) over the lives of eight waves spread over the grid
+        double ticks = 0, shader = 0;
+        if (!latency_call) for (int k = 0; k < 8; k++) { const unsigned long long* c = h_clk + 4 * k; if (c[2] > c[0] && c[3] > c[1]) { ticks += (double)(c[2] - c[0]); shader += (double)(c[3] - c[1]); } }
+        st.clock_mhz = ticks > 0 ? (float)(100.0 * shader / ticks) : 0.f;
         std::lock_guard<std::mutex> lk(stat_mu);
         last_stat = st;
     }
@@ -419,7 +421,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "prove_chunk(%zu): enqueue %.2f ms, wait %.2f ms, serialise %.2f ms\n", n, ms(tc0, tc1), ms(tc1, tc2), ms(tc2, tc3));
         auto mhz = [&](int k) { const unsigned long long* c = h_clk + 4 * k; return c[2] > c[0] && c[3] > c[1] ? 100.0 * (double)(c[3] - c[1]) / (double)(c[2] - c[0]) : 0.0; };
-        if (!latency_call) fprintf(stderr, "prove_chunk(%zu): shader clock (one workgroup in the middle of each launch): transforms %.0f / %.0f / %.0f MHz, Z kernel %.0f MHz; stages %.2f / %.2f / %.2f / %.2f ms\n", n, mhz(1), mhz(2), mhz(3), mhz(0),
+        if (!latency_call) fprintf(stderr, "prove_chunk(%zu): shader clock (one workgroup in the middle of each launch): transforms %.0f / %.0f / %.0f MHz, Z kernel %.0f MHz (eight waves); stages %.2f / %.2f / %.2f / %.2f ms\n", n, mhz(8), mhz(9), mhz(10), (double)ln.stat.clock_mhz,
                                    ln.stage_ms[0], ln.stage_ms[1], ln.stage_ms[2], ln.stage_ms[3]);
     }
 }

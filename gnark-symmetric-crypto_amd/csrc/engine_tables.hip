@@ -473,8 +473,8 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
-    ln.h_in.alloc(176 * B); ln.h_rs.alloc(64 * B); ln.h_glv.alloc(2 * MSM_FEW_PROOFS); ln.h_out.alloc(256 * B); ln.h_flags.alloc((B + 3) / 4 * 4); ln.h_status.alloc(B); ln.h_words.alloc(24);
-    ln.d_clk.alloc(16); HIP_CHECK(hipMemsetAsync(ln.d_clk.p, 0, 128, ln.stream));
+    ln.h_in.alloc(176 * B); ln.h_rs.alloc(64 * B); ln.h_glv.alloc(2 * MSM_FEW_PROOFS); ln.h_out.alloc(256 * B); ln.h_flags.alloc((B + 3) / 4 * 4); ln.h_status.alloc(B); ln.h_words.alloc(56);
+    ln.d_clk.alloc(48); HIP_CHECK(hipMemsetAsync(ln.d_clk.p, 0, 48 * 8, ln.stream));      // [0, 32): the Z kernel's eight samples; [32, 44): the three transform kernels
     ln.d_inputs.alloc(176 * B); ln.d_rs.alloc(64 * B); ln.d_out.alloc(256 * B); ln.d_flags.alloc((B + 3) / 4 * 4); ln.d_status.alloc(B); ln.d_fsync.alloc(2); ln.d_glv.alloc(2 * MSM_FEW_PROOFS);
     // (the buffers that will hold secrets start out clean, so that "nothing of a call is left" can be checked from the first call on)
     HIP_CHECK(hipMemsetAsync(ln.d_inputs.p, 0, ln.d_inputs.bytes(), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_rs.p, 0, ln.d_rs.bytes(), ln.stream)); HIP_CHECK(hipMemsetAsync(ln.d_glv.p, 0, ln.d_glv.bytes(), ln.stream));

@@ -281,8 +281,11 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArg
     // XCD-aware order: workgroups go round-robin over the 8 XCDs by linear id and each XCD has its own L2.  Every wave of a slice
     // (all windows, all groups of proofs) gathers from the same table rows, so a slice is placed on ONE XCD (consecutive ids there).
     const size_t G = a.batch / 64, GW = G * (size_t)a.nwin, L = blockIdx.x, S8 = a.nslices & ~(size_t)7;
-    const bool stamp = a.clk && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
-    if (stamp) { a.clk[0] = wall_clock64(); a.clk[1] = clock64(); }
+    // clock stamps: eight waves spread over the launch (at 1/16, 3/16, ... of the grid) each record {100 MHz clock, shader clock} at their start and end
+    const uint32_t eighth = gridDim.x / 8;
+    const bool stamp = a.clk && eighth && threadIdx.x == 0 && blockIdx.x % eighth == eighth / 2 && blockIdx.x / eighth < 8;
+    unsigned long long* const clk = a.clk + (stamp ? 4 * (blockIdx.x / eighth) : 0);
+    if (stamp) { clk[0] = wall_clock64(); clk[1] = clock64(); }
     size_t slice, rem;
     if (L < S8 * GW) { const size_t xcd = L & 7, i = L >> 3; slice = (i / GW) * 8 + xcd; rem = i % GW; }
     else { slice = L / GW; rem = L % GW; }
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArg
         if (!acc.inf && F::is_zero(acc.zz)) acc = accumulate_window<F, true, WIDE>(a, k0, k1, j, p);
     }
     C::store_xyzz(reinterpret_cast<fe*>(a.partial) + ((slice * a.nwin + j) * a.batch + p) * (4 * F::WORDS), acc);
-    if (stamp) { a.clk[2] = wall_clock64(); a.clk[3] = clock64(); }
+    if (stamp) { clk[2] = wall_clock64(); clk[3] = clock64(); }
 }
 
 // The latency path: a handful of proofs (a single Prove call).  With lanes = proofs a wave would do 64 additions per useful one, so

@@ -202,8 +202,8 @@ struct MsmWinArgs {
     const uint4* digits; size_t batch;
     size_t nslices, per;           // per: a multiple of 8
     void* partial;                 // G1Xyzz / G2Xyzz [nslices][nwin][batch]
-    // diagnostics (bench.py's VALU roofline): the workgroup in the middle of the grid stamps {100 MHz clock, shader clock} when it starts and
-    // when it ends -> clk[0..3]; their ratio is the shader clock the launch really ran at (the chip is power-limited).  nullptr: no stamps.
+    // diagnostics (bench.py's VALU roofline): eight waves spread over the grid stamp {100 MHz clock, shader clock} when they start and when they
+    // end -> clk[4 k .. 4 k + 3], k < 8; the ratios are the shader clock the launch really ran at (the chip is power-limited).  nullptr: no stamps.
     unsigned long long* clk = nullptr;
     // TEST HOOK (timing experiment, WRONG sums): every gather's entry index is masked to this many bits, i.e. the kernel does the same arithmetic over rows of
     // 2^bits entries — the L2 hit rate it would have with that many lanes per entry in flight.  0 = off.
