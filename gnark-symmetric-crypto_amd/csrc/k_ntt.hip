@@ -397,18 +397,23 @@ __global__ __launch_bounds__(512) void k_ntt_pointwise_strided(NttPlan pl, fe* v
             t.put(e, q, F::unpack(ld_stream(vec + idx * batch + q0 + q)));
         }
         __syncthreads();
-        dit_run<true>(t, u4, q, Llo, L - 1, L, Llo, g, pl, G);
-        auto last_dit = [&](uint32_t e1, fe9& lo, fe9& hi) {   // last DIT stage (s = L-1): pair (e1, e1 + G/2)
-            const uint32_t e2 = e1 + G / 2;
-            const uint32_t ex = ((e1 << Llo) + g) & ((1u << (L - 1)) - 1);
-            const fe9 u = F::norm(t.get(e1, q));
-            const fe9 v = mulw<false>(t.get(e2, q), pl.tw_fwd, ex, pl.qr);
-            const fe9 x1 = F::norm(F::add(u, v)), x2 = F::norm(F::sub(u, v));      // tight; |value| <= 2^256/r + 8 * 1.1 < 15 r
-            if (k == 0) { lo = x1; hi = x2; }
-            else { lo = F::mul(lo, x1); hi = F::mul(hi, x2); }                                             // a*b in (-1.4r, 2.4r)
-        };
-        last_dit(u4, lo0, hi0);
-        last_dit(u4 + G / 4, lo1, hi1);
+        dit_run<true>(t, u4, q, Llo, L - 2, L, Llo, g, pl, G);
+        {
+            // The last two forward stages (s = L-2, L-1) couple this thread's own four elements u4 + {0, 1, 2, 3} G/4: in registers, straight into the
+            // pointwise product (stage L-2 pairs (e0, e1), (e2, e3); stage L-1 pairs (e0, e2), (e1, e3); twiddle exponents of the plain radix-2 stages).
+            const uint32_t e0 = u4, e1 = u4 + G / 4, e2 = u4 + G / 2, e3 = u4 + 3 * (G / 4);
+            const uint32_t g0 = (e0 << Llo) + g, g1 = (e1 << Llo) + g, g2 = (e2 << Llo) + g;
+            const uint32_t m1 = (1u << (L - 2)) - 1, m2 = (1u << (L - 1)) - 1;
+            const uint32_t exA = (g0 & m1) << 1, exB = (g2 & m1) << 1, exC = g0 & m2, exD = g1 & m2;
+            const fe9 n0 = F::norm(t.get(e0, q)), n2 = F::norm(t.get(e2, q));
+            const fe9 v1 = mulw<false>(t.get(e1, q), pl.tw_fwd, exA, pl.qr), v3 = mulw<false>(t.get(e3, q), pl.tw_fwd, exB, pl.qr);
+            const fe9 a0 = F::norm(F::add(n0, v1)), a1 = F::sub(n0, v1);
+            const fe9 w2 = mulw<false>(F::add(n2, v3), pl.tw_fwd, exC, pl.qr), w3 = mulw<false>(F::sub(n2, v3), pl.tw_fwd, exD, pl.qr);
+            // tight; |value| <= 2^256/r + 9 * 1.1 < 16 r
+            const fe9 x0 = F::norm(F::add(a0, w2)), x2 = F::norm(F::sub(a0, w2)), x1 = F::norm(F::add(a1, w3)), x3 = F::norm(F::sub(a1, w3));
+            if (k == 0) { lo0 = x0; hi0 = x2; lo1 = x1; hi1 = x3; }
+            else { lo0 = F::mul(lo0, x0); hi0 = F::mul(hi0, x2); lo1 = F::mul(lo1, x1); hi1 = F::mul(hi1, x3); }      // a*b in (-1.6r, 2.6r)
+        }
         __syncthreads();
     }
     if (EVAL == 1) {
