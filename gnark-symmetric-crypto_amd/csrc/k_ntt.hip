@@ -338,23 +338,12 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
     const uint32_t q = threadIdx.x % P, u4 = threadIdx.x / P;
     const ClkStamp cs(pl.clk, 1);
     Tile t{smem, Cn * P};
-    // Llo - 2 inverse stages come before the fused middle and Llo - 2 forward stages after it.  An odd count leaves a single stage over, and that stage
-    // pairs (e, e + Cn/2) — for the thread's elements u4 + k Cn/4 exactly the pairs (k = 0, 2) and (k = 1, 3) of what it loads / stores: the first inverse
-    // stage then runs on the loaded values and the last forward stage on the values about to be stored, without an LDS round trip of their own.
-    const bool odd = ((Llo - 2) & 1) != 0;
-    const uint32_t eA = u4, eB = u4 + Cn / 4, eC = u4 + Cn / 2, eD = u4 + 3 * (Cn / 4);
-    const size_t rowA = ((size_t)b << Llo) + eA, rowB = ((size_t)b << Llo) + eB, rowC = ((size_t)b << Llo) + eC, rowD = ((size_t)b << Llo) + eD;
-    {
-        const fe9 xA = F::unpack(ld_stream(vec + rowA * batch + q0 + q)), xB = F::unpack(ld_stream(vec + rowB * batch + q0 + q));
-        const fe9 xC = F::unpack(ld_stream(vec + rowC * batch + q0 + q)), xD = F::unpack(ld_stream(vec + rowD * batch + q0 + q));
-        if (odd) {      // inverse stage s = Lhi: twiddle exponent = (row mod 2^(L-1-s)) << s
-            const uint32_t hgm = (1u << (L - 1 - Lhi)) - 1;
-            t.put(eA, q, F::norm(F::add(xA, xC))); t.put(eC, q, mulw<false>(F::sub(xA, xC), pl.tw_inv, ((uint32_t)rowA & hgm) << Lhi, pl.qr));
-            t.put(eB, q, F::norm(F::add(xB, xD))); t.put(eD, q, mulw<false>(F::sub(xB, xD), pl.tw_inv, ((uint32_t)rowB & hgm) << Lhi, pl.qr));
-        } else { t.put(eA, q, xA); t.put(eB, q, xB); t.put(eC, q, xC); t.put(eD, q, xD); }
+    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
+        const size_t idx = ((size_t)b << Llo) + e;
+        t.put(e, q, F::unpack(ld_stream(vec + idx * batch + q0 + q)));
     }
     __syncthreads();
-    dif_run<false>(t, u4, q, odd ? Lhi + 1 : Lhi, L - 2, odd ? 1 : 0, L, Llo, b, pl, Cn);      // all but the last two inverse stages
+    dif_run<false>(t, u4, q, Lhi, L - 2, 0, L, Llo, b, pl, Cn);      // all but the last two inverse stages
     {
         // The last two inverse stages, the scaling and the first two forward stages couple the SAME four consecutive elements 4 u4 .. 4 u4 + 3: they run in
         // registers — two LDS round trips, two barriers and the range reductions between them are gone, and the twiddles that are 1 for every thread
@@ -374,16 +363,10 @@ __global__ __launch_bounds__(256) void k_ntt_mid_contig(NttPlan pl, fe* v0, fe* 
         t.put(e0 + 1, q, F::add(c1, w3)); t.put(e0 + 3, q, F::sub(c1, w3));
     }
     __syncthreads();
-    dit_run<false>(t, u4, q, 2, odd ? Llo - 1 : Llo, L, Llo, b, pl, Cn);      // (an even number of stages: rounds only)
-    if (odd) {      // forward stage s = Llo - 1 on the pairs (eA, eC), (eB, eD): twiddle exponent = (row mod 2^s) << (L-1-s)
-        const int sl = Llo - 1; const uint32_t msk = (1u << sl) - 1;
-        const fe9 uA = F::norm(t.get(eA, q)), uB = F::norm(t.get(eB, q));
-        const fe9 vC = mulw<false>(t.get(eC, q), pl.tw_fwd, ((uint32_t)rowA & msk) << (L - 1 - sl), pl.qr), vD = mulw<false>(t.get(eD, q), pl.tw_fwd, ((uint32_t)rowB & msk) << (L - 1 - sl), pl.qr);
-        store_lazy(vec + rowA * batch + q0 + q, F::add(uA, vC), pl.qr); store_lazy(vec + rowC * batch + q0 + q, F::sub(uA, vC), pl.qr);
-        store_lazy(vec + rowB * batch + q0 + q, F::add(uB, vD), pl.qr); store_lazy(vec + rowD * batch + q0 + q, F::sub(uB, vD), pl.qr);
-    } else {
-        store_lazy(vec + rowA * batch + q0 + q, t.get(eA, q), pl.qr); store_lazy(vec + rowB * batch + q0 + q, t.get(eB, q), pl.qr);
-        store_lazy(vec + rowC * batch + q0 + q, t.get(eC, q), pl.qr); store_lazy(vec + rowD * batch + q0 + q, t.get(eD, q), pl.qr);
+    dit_run<false, true>(t, u4, q, 2, Llo, L, Llo, b, pl, Cn);
+    for (uint32_t e = u4; e < Cn; e += Cn / 4) {
+        const size_t idx = ((size_t)b << Llo) + e;
+        store_lazy(vec + idx * batch + q0 + q, t.get(e, q), pl.qr);
     }
     cs.end();
 }
