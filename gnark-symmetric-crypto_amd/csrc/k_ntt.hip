@@ -20,6 +20,14 @@
 //   K3 strided DIT tail (a,b) + pointwise + strided DIF head (d) | K4 contiguous DIF tails of c and d, h = (S - D) / 2.
 // Every kernel stages a tile of P proofs x 2^Lhi (or 2^Llo) elements in LDS, limb-major, two radix-2 stages
 // per barrier; global accesses are P*32 = 128-byte segments.
+//
+// Evaluation form (k_quot_bases.hip; what batch calls run): only the transforms of a and b — K1, K2, K3 — and K3 ends at d = a b on the zeta-coset, whose
+// signed digits it writes for the Z sum.  The step is power-limited: what buys time in these kernels is fewer instructions, so
+//   * K1 takes byte planes (the small-integer witness path) as plain integers: the first two stages of a ternary tile are twiddles scaled by integers in [-4, 4];
+//   * K2 runs the last two inverse stages, the scaling and the first two forward stages of a thread's four consecutive elements in registers (the
+//     pairs whose twiddle is 1 for every thread cost no product);
+//   * K3 runs its last two forward stages in registers straight into the pointwise product, canonicalises with three conditional subtractions and takes
+//     the digits of the bench configuration's width (c = 17) at compile-time bit offsets.
 #include "kernels.hpp"
 #include "bn254_fp29.hpp"
 
