@@ -31,7 +31,7 @@ EngineConfig config_from_env() {
     if (c.small_lanes > 8) throw std::runtime_error("GSC_SMALL_LANES must be at most 8");
     // test-only knobs (no product setting, no profile uses a non-default value): honoured with the load-time test-hooks flag only
     const bool hooks = test_hooks_enabled();
-    c.min_split = (size_t)(hooks ? env_int("GSC_MIN_SPLIT", 256) : 256);
+    c.min_split = (size_t)(hooks ? env_int("GSC_MIN_SPLIT", 0) : 0);
     c.bit_groups = env_int("GSC_BIT_GROUPS", 1);
     c.window_z = env_int("GSC_WINDOW_Z", 0);
     c.window_w = env_int("GSC_WINDOW_W", 0);
@@ -167,15 +167,17 @@ void Algorithm::debug_compute_d(const uint8_t* ab_be, size_t m, uint8_t* d_out) 
     HIP_CHECK(hipStreamSynchronize(ln.stream));
 }
 // one replica: cut the request list into chunks (multiples of 64 proofs, at most one lane's capacity) and let worker threads pull
-// chunks, each on whichever lane is free.  A call with at least 2 * min_split statements that is alone on the replica is cut into as
-// many chunks as there are lanes (the latency-bound witness stage of one chunk hides under the kernels of the other); when other
-// calls are in flight it stays whole and the overlap happens between calls instead (measured on AES-128, two callers: +4 %).
+// chunks, each on whichever lane is free.  A call that fits one lane stays whole: cutting a lone 1024-statement AES-128 call over
+// the two lanes doubles the latency-bound level launches of the witness stage, and the lanes' streams share a hardware queue more
+// often than not, so nothing hides (round 4, profiles/r04_aes128_lanes.txt: 3 255 proofs/s cut, 3 341 - 3 362 whole; round 2 had
+// measured +4 % for cutting, on slower MSM kernels).  min_split > 0 (test hook) brings the cut back: the tests use it to cover
+// chunked calls with small batches.
 static void prove_on_replica(AlgorithmImpl& a, const ProofRequest* reqs, size_t n, ProofResult* results, DebugVectors* debug_first, KernelStat* stat, std::mutex* stat_mu) {
     if (!n) return;
     const size_t nl = a.full_lanes, lane_cap = a.lanes[0]->cap;      // only full lanes take the chunks of a big call
     size_t nchunks = (n + lane_cap - 1) / lane_cap;
     struct InFlight { std::atomic<int>& c; int seen; explicit InFlight(std::atomic<int>& x) : c(x), seen(x.fetch_add(1) + 1) {} ~InFlight() { c.fetch_sub(1); } } me(a.calls_in_flight);
-    if (nl > 1 && me.seen == 1 && n >= 2 * a.cfg.min_split) { const size_t want = (nchunks + nl - 1) / nl * nl; nchunks = want; }
+    if (nl > 1 && a.cfg.min_split && me.seen == 1 && n >= 2 * a.cfg.min_split) { const size_t want = (nchunks + nl - 1) / nl * nl; nchunks = want; }
     size_t chunk = ((n + nchunks - 1) / nchunks + 63) / 64 * 64;
     if (chunk > lane_cap) chunk = lane_cap;
     nchunks = (n + chunk - 1) / chunk;
