@@ -235,7 +235,7 @@ __global__ void k_ntt_constants(const fe* omega, const fe* omega_inv, const fe* 
 }
 
 // TEST HOOK kernel: element-wise field operations on canonical inputs, through the radix-2^29 implementation, canonical outputs.
-// op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inv, 5 fmms(a,b,b,a+... see host doc), 6 neg; lazy: apply the op `chain` times on a running value
+// op: 0 mul, 1 add, 2 sub, 3 sqr, 4 inv, 5 fmms(a,b,b,a+... see host doc), 6 neg, 8 (Fr only) wave_batch_inverse of k_solver.hip; lazy: apply the op `chain` times on a running value
 template <class F>
 __global__ void k_field_ops(int op, const fe* a, const fe* b, fe* out, size_t n, int chain) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -262,6 +262,7 @@ __global__ void k_field_ops(int op, const fe* a, const fe* b, fe* out, size_t n,
 
 void launch_field_ops(int field, int op, const fe* a, const fe* b, fe* out, size_t n, int chain, hipStream_t s) {
     if (!n) return;
+    if (field == 1 && op == 8) { launch_wave_inverse(a, out, n, s); return; }      // the generic solver's own inversion (8 x 32-bit limbs; k_solver.hip)
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
     if (field == 0) hipLaunchKernelGGL(k_field_ops<Fp29>, grid, block, 0, s, op, a, b, out, n, chain);
     else hipLaunchKernelGGL(k_field_ops<Fr29>, grid, block, 0, s, op, a, b, out, n, chain);

@@ -795,6 +795,21 @@ void launch_assign_aes(const uint8_t* inputs, int keylen, fe* W, size_t batch, h
 void launch_prep_rs(const uint8_t* rs, fe* W, size_t n_wires, size_t batch, const uint8_t* mask_in, fe* mask_out, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_rs, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, rs, W, n_wires, batch, mask_in, mask_out);
 }
+// TEST HOOK kernel: the batch solver's wave-wide inversion on canonical inputs, canonical outputs; 0 stays 0 (the solver lends such a lane a 1)
+namespace {
+__global__ __launch_bounds__(64) void k_wave_inverse(const fe* a, fe* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    fe x = i < n ? Fr::to_mont(load_fe(a + i)) : Fr::one();
+    const bool z = Fr::is_zero(x);
+    if (z) x = Fr::one();
+    const fe r = wave_batch_inverse(x);
+    if (i < n) store_fe(out + i, z ? Fr::zero() : Fr::from_mont(r));
+}
+}  // namespace
+void launch_wave_inverse(const fe* a, fe* out, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_wave_inverse, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a, out, n);
+}
+
 void launch_solver_count_level(const SolverArgs& a, uint32_t level_width, hipStream_t s) {
     if (!level_width) return;
     hipLaunchKernelGGL(k_solver_count, dim3((unsigned)(a.batch / 64), level_width), dim3(64 * COUNT_WAVES), 256 * 64 * sizeof(uint32_t), s, a);

@@ -36,6 +36,7 @@ void launch_ntt_constants(const fe* omega, const fe* omega_inv, const fe* n_inv,
 
 // TEST HOOK: radix-2^29 field self-test.  field 0 = Fp, 1 = Fr; a, b, out: n canonical 32-byte little-endian values (device memory).
 void launch_field_ops(int field, int op, const fe* a, const fe* b, fe* out, size_t n, int chain, hipStream_t s);
+void launch_wave_inverse(const fe* a, fe* out, size_t n, hipStream_t s);      // TEST HOOK (field 1, op 8 of launch_field_ops): k_solver's division, 64 values per inversion
 
 // TEST HOOK / diagnostics: one resident wave records n samples {100 MHz clock, shader clock} `interval` 100 MHz ticks apart into out[2 n]
 void launch_clock_trace(unsigned long long* out, uint32_t n, uint32_t interval_100mhz_ticks, hipStream_t s);

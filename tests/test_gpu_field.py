@@ -57,3 +57,19 @@ def test_operation_chains_stay_exact(gsc, field, mod):
             r = (r * y - y * x) % mod
         want.append(r)
     assert gsc.debug_field_ops(field, 5, a, b, chain=6) == want
+
+
+def test_the_batch_solvers_division_inverts_64_values_with_one_inversion(gsc):
+    """k_solver's wave_batch_inverse (Montgomery's trick across the lanes of a wave; AES-V2's 2 080 / 2 384 divisions per proof — gnark
+    solveR1C / divByCoeff): every lane's result must be its own value's inverse whatever its neighbours hold — edge
+    values, equal values, zeros (which the solver never divides by: it lends such a lane a 1), a ragged last wave."""
+    rnd = random.Random(77)
+    edge = [1, 2, R - 1, R - 2, (R - 1) // 2, (R + 1) // 2, 1 << 253, (1 << 253) - 1, pow(2, 256, R), pow(2, -256, R), 3, 5]
+    vals = edge + [rnd.randrange(1, R) for _ in range(64 - len(edge))]                      # one full wave of distinct values
+    vals += [7] * 64                                                                         # a wave of equal values
+    vals += [0 if i % 3 == 0 else rnd.randrange(1, R) for i in range(64)]                    # zeros among the lanes
+    vals += [0] * 64                                                                         # nothing to divide by at all
+    vals += [rnd.randrange(1, 1 << 16) for _ in range(64)] + [R - rnd.randrange(1, 1 << 16) for _ in range(64)]      # tiny and -tiny
+    vals += [rnd.randrange(1, R) for _ in range(37)]                                         # ragged tail
+    got = gsc.debug_field_ops(1, 8, vals, vals)
+    assert got == [pow(x, R - 2, R) for x in vals]
