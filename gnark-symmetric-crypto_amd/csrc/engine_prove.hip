@@ -175,6 +175,8 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     const auto tc0 = std::chrono::steady_clock::now();
     // staging is the lane's pinned memory; what it holds of the statements' secrets (keys, randomness, masks) is cleared when the call leaves, however it leaves
     struct StagingWiper { Lane& l; size_t B; ~StagingWiper() { explicit_bzero(l.h_in.p, 176 * B); explicit_bzero(l.h_rs.p, 64 * B); explicit_bzero(l.h_glv.p, l.h_glv.bytes()); if (l.h_mask.p) explicit_bzero(l.h_mask.p, 32 * B); } } wipe_staging{ln, B};
+    // a call that leaves by an exception must not leave work behind on the lane's other streams (the next call would share its buffers with it)
+    struct Drain { Lane& l; int live = std::uncaught_exceptions(); ~Drain() { if (std::uncaught_exceptions() > live) { (void)hipStreamSynchronize(l.side); (void)hipStreamSynchronize(l.side2); (void)hipStreamSynchronize(l.stream); } } } drain{ln};
     uint8_t* const h_in = ln.h_in.p; uint8_t* const h_rs = ln.h_rs.p; GlvSplit* const h_glv = ln.h_glv.p;
     pack_inputs(reqs, n, B, h_in, h_rs);
     ln.d_inputs.upload(h_in, 176 * B, ln.stream);
@@ -321,6 +323,15 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     const bool few_call = ln.n_real <= (size_t)cfg.few_max && cfg.few_path;
     const bool use_zfew = few_call && mZfew.nflat;                 // the latency layout holds the key's own Z: coefficient form
     const bool eval = quotient_eval && !use_zfew;
+    const bool z_digits_ready = eval && fuse_z_digits && !few_call;
+    // The evaluation-form quotient of a batch call reads a and b (rows or byte planes) and writes d over a and its digits into the Z set's own
+    // digit buffer; the wire-set sums (A, B1, B2, K, and c over mC) read W and c and recode into d_digits_w.  Nothing is shared, so the
+    // three quotient kernels go to the lane's third stream and the wire sets' thin tails (slice reductions, Horner chains, recoders: 5 ms of
+    // a 1024-statement call's 54, none of it chip-filling) run under them; the Z sum waits for both.  Measured (profiles/r04k_overlap_quotient.txt):
+    // 1024 statements +3.5 %, AES-128 +2.8 %, 8192 +0.1 %; calls of 64 / 256 statements lose 5 % / 2 % (they already run beside other
+    // calls on the small lanes, the extra stream only adds waits), hence the threshold.
+    const bool overlap_q = z_digits_ready && !dbg && (cfg.overlap_quotient < 0 ? B >= OVERLAP_QUOTIENT_MIN : cfg.overlap_quotient != 0);
+    hipStream_t qs = overlap_q ? ln.side2 : ln.stream;
     if (eval) {
         if (dbg) {      // the debug vector is h itself: the coefficient-form kernels on copies (they overwrite their inputs)
             DevBuf<fe> ta(domain_n * B), tb(domain_n * B), tc(domain_n * B);
@@ -330,13 +341,13 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
             HIP_CHECK(launch_compute_h(plan, ta.p, tb.p, tc.p, n_constraints, B, ln.stream, 0));
             fetch_column(ln, ta.p, domain_n, B, 0, dbg->H);
         }
-        if (fuse_z_digits && !few_call) HIP_CHECK(launch_compute_d_digits(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, QuotDigits{ln.d_digits.p, mZ.c, mZ.nwin}, ln.stream, narrow));
+        if (overlap_q) HIP_CHECK(hipStreamWaitEvent(qs, ln.ev[1], 0));      // the end of the witness stage
+        if (fuse_z_digits && !few_call) HIP_CHECK(launch_compute_d_digits(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, QuotDigits{ln.d_digits.p, mZ.c, mZ.nwin}, qs, narrow));
         else HIP_CHECK(launch_compute_d(plan, ln.d_A.p, ln.d_B.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0, narrow));
     } else HIP_CHECK(launch_compute_h(plan, ln.d_A.p, ln.d_B.p, ln.d_C.p, n_constraints, B, ln.stream, few_call ? ln.n_real : 0, narrow));      // latency path: the statements' columns only
-    HIP_CHECK(hipEventRecord(ln.ev[2], ln.stream));
+    HIP_CHECK(hipEventRecord(ln.ev[2], qs));
     if (dbg && !eval) fetch_column(ln, ln.d_A.p, domain_n, B, 0, dbg->H);
     // 3. MSMs.  (With fuse_z_digits the digits of d are already in the lane's Z digit buffer; every other set recodes into d_digits_w.)
-    const bool z_digits_ready = eval && fuse_z_digits && !few_call;
     // A and B1 first: the two scalar multiplications of the assembly only need those two sums and run on a side stream
     // beside the remaining MSMs.
     if (!early_ab) {
@@ -360,6 +371,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         HIP_CHECK(hipMemsetAsync(ln.d_C.p + domain_n * B, 0, B * sizeof(fe), ln.stream));
         run_msm_g1(ln, mC, ln.d_C.p, 1, B, ln.d_sumC.p);
     }
+    if (overlap_q) HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev[2], 0));           // d and its digits
     run_msm_g1(ln, use_zfew ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call, false, z_digits_ready);
     if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
     flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
