@@ -469,7 +469,20 @@ void AlgorithmImpl::init_key(const R1csFile& cs, const PkFile& key) {
 
 void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     ln.cap = B;
-    HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side)); HIP_CHECK(hipStreamCreate(&ln.side2));
+    // HIP spreads a process's streams over GPU_MAX_HW_QUEUES (4) hardware queues PER PRIORITY LEVEL, round-robin: with ten streams of one
+    // priority (a full lane and two small ones, three streams each) a lane's side stream lands in the queue of another lane's main stream and
+    // that lane's kernels wait behind a 3 ms chain of sixteen waves.  The three roles therefore take the three priority levels — three pools
+    // of queues, no sharing with the default lane counts — and the levels suit them: the side stream carries thin chains on a call's
+    // critical path (scalar multiplications, G2 Horner), the third stream bulk work that only has to finish before the Z sum (the quotient
+    // of a big call) or beside an otherwise idle chip (a single Prove's B2 sum).  Measured against GPU_MAX_HW_QUEUES=8 in
+    // profiles/r04l_hw_queues.txt.  GSC_STREAM_PRIORITIES=0: plain streams.
+    int least = 0, greatest = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (cfg.stream_priorities && least != greatest) {
+        HIP_CHECK(hipStreamCreateWithPriority(&ln.stream, hipStreamDefault, (least + greatest) / 2));
+        HIP_CHECK(hipStreamCreateWithPriority(&ln.side, hipStreamDefault, greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&ln.side2, hipStreamDefault, least));
+    } else { HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side)); HIP_CHECK(hipStreamCreate(&ln.side2)); }
     for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
