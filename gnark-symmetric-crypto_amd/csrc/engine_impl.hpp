@@ -107,7 +107,6 @@ class AlgorithmImpl {
     DevBuf<uint32_t> ws_tiny, ws_parts, ws_bits, ws_twire, ws_levels, ws_rtiny, ws_rgen, ws_rtwire; DevBuf<long long> ws_tcoef, ws_rtcoef;
     DevBuf<uint8_t> ws_cls_a, ws_cls_b, ws_cls_c;      // per constraint row: 0 = byte plane, 1 = 32-byte element
     void init_small(const SolverProgram& sp);
-    static constexpr size_t OVERLAP_QUOTIENT_MIN = 512;      // batch calls of at least this many statements run the quotient beside the wire-set MSMs (prove_chunk)
     std::atomic<uint64_t> small_fallbacks{0};      // chunks that had to be solved again generically (gsc_describe)
     // NTT
     DevBuf<int32_t> tw_fwd, tw_inv, tw_inv_plain, qr; DevBuf<fe> scale_mid, scale_mid_plain, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n
@@ -159,7 +158,7 @@ class AlgorithmImpl {
     std::vector<std::unique_ptr<Lane>> lanes;
     size_t cap = 0;                     // proofs per full lane = the largest chunk
     size_t full_lanes = 0;              // lanes [0, full_lanes) hold `cap` proofs; the rest are small lanes (SMALL_LANE_CAP)
-    static constexpr size_t SMALL_LANE_CAP = 512;
+    static constexpr size_t SMALL_LANE_CAP = 1024;     // 512 until round 4: two 1024-statement calls side by side prove 6 % more than one after the other on the full lane (profiles/r04m_lanes.txt)
 
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf);
     ~AlgorithmImpl() { lanes.clear(); if (stream) (void)hipStreamDestroy(stream); }

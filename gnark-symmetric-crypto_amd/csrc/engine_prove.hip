@@ -328,9 +328,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     // digit buffer; the wire-set sums (A, B1, B2, K, and c over mC) read W and c and recode into d_digits_w.  Nothing is shared, so the
     // three quotient kernels go to the lane's third stream and the wire sets' thin tails (slice reductions, Horner chains, recoders: 5 ms of
     // a 1024-statement call's 54, none of it chip-filling) run under them; the Z sum waits for both.  Measured (profiles/r04k_overlap_quotient.txt):
-    // 1024 statements +3.5 %, AES-128 +2.8 %, 8192 +0.1 %; calls of 64 / 256 statements lose 5 % / 2 % (they already run beside other
-    // calls on the small lanes, the extra stream only adds waits), hence the threshold.
-    const bool overlap_q = z_digits_ready && !dbg && (cfg.overlap_quotient < 0 ? B >= OVERLAP_QUOTIENT_MIN : cfg.overlap_quotient != 0);
+    // 64 / 256 / 512 / 1024 statements per call +2 / +8 / +6 / +3.5 %, 8192 +0.1 %, AES-128 1024 / 256 per call +2.8 / +7 % — once the lanes'
+    // streams stopped sharing hardware queues (alloc_lane); before that, calls on the small lanes lost 2 - 5 % to it.
+    const bool overlap_q = z_digits_ready && !dbg && cfg.overlap_quotient != 0;
     hipStream_t qs = overlap_q ? ln.side2 : ln.stream;
     if (eval) {
         if (dbg) {      // the debug vector is h itself: the coefficient-form kernels on copies (they overwrite their inputs)

@@ -274,9 +274,9 @@ def test_engine_options_do_not_change_the_proofs():
                   {"GSC_QUOTIENT_EVAL": "0"}, {"GSC_QUOTIENT_EVAL": "0", "GSC_BIT_GROUPS": "0"},
                   # GSC_FUSE_Z_DIGITS=0: the last quotient kernel writes d and a recoding pass makes the digits, instead of writing the digits itself
                   {"GSC_FUSE_Z_DIGITS": "0"}, {"GSC_FUSE_Z_DIGITS": "0", "GSC_WINDOW_Z": "11"},
-                  # GSC_OVERLAP_QUOTIENT: the quotient kernels on a stream of their own beside the wire-set MSMs (the default for calls of
-                  # 512 statements and more: forced on for this small batch, and off)
-                  {"GSC_OVERLAP_QUOTIENT": "1"}, {"GSC_OVERLAP_QUOTIENT": "1", "GSC_LANES": "2"}, {"GSC_OVERLAP_QUOTIENT": "0"}):
+                  # GSC_OVERLAP_QUOTIENT=0: the quotient kernels before the wire-set MSMs on one stream instead of beside them on the lane's third;
+                  # GSC_STREAM_PRIORITIES=0: the lane's streams all at the default priority (shared hardware queues)
+                  {"GSC_OVERLAP_QUOTIENT": "0"}, {"GSC_OVERLAP_QUOTIENT": "0", "GSC_LANES": "2"}, {"GSC_STREAM_PRIORITIES": "0"}, {"GSC_STREAM_PRIORITIES": "0", "GSC_LANES": "2"}):
         assert _digest(extra) == base, extra
 
 
@@ -286,7 +286,7 @@ def test_engine_options_do_not_change_the_proofs_aes(aes_keys):
     assert os.path.exists(pk_path)
     base = _digest({}, 1, pk_path)
     for extra in ({"GSC_BIT_GROUPS": "0"}, {"GSC_BIT_GROUPS": "2"}, {"GSC_ROW_MARGIN_BITS": "-6"}, {"GSC_WINDOW_W": "9"}, {"GSC_QUOTIENT_EVAL": "0"}, {"GSC_FUSE_Z_DIGITS": "0"},
-                  {"GSC_OVERLAP_QUOTIENT": "1"}):
+                  {"GSC_OVERLAP_QUOTIENT": "0"}, {"GSC_STREAM_PRIORITIES": "0"}):
         assert _digest(extra, 1, pk_path) == base, extra
 
 
