@@ -29,6 +29,8 @@ EngineConfig config_from_env() {
     c.lanes = env_int("GSC_LANES", 0);
     c.small_lanes = env_int("GSC_SMALL_LANES", -1);
     if (c.small_lanes > 8) throw std::runtime_error("GSC_SMALL_LANES must be at most 8");
+    c.small_lane_cap = env_int("GSC_SMALL_LANE_CAP", 0);
+    if (c.small_lane_cap < 0 || c.small_lane_cap % 64) throw std::runtime_error("GSC_SMALL_LANE_CAP must be a multiple of 64");
     // test-only knobs (no product setting, no profile uses a non-default value): honoured with the load-time test-hooks flag only
     const bool hooks = test_hooks_enabled();
     c.min_split = (size_t)(hooks ? env_int("GSC_MIN_SPLIT", 0) : 0);

@@ -36,7 +36,8 @@ struct EngineConfig {
                                  // split over them in contiguous shares — a single FFI host process drives all the GPUs of a node
     size_t max_batch = 1024;     // GSC_MAX_BATCH: proofs per device batch = capacity of every lane (rounded to a multiple of 64)
     int lanes = 0;               // GSC_LANES: concurrent HIP streams, each with batch buffers of its own, handed to concurrent calls / chunks; 0 = 1 for ChaCha20-V3, 2 for AES-V2
-    int small_lanes = -1;        // GSC_SMALL_LANES: extra lanes of 512 proofs for calls that fit them (several small calls in flight at once); -1 = 2 for ChaCha20-V3, 0 for AES-V2
+    int small_lanes = -1;        // GSC_SMALL_LANES: extra lanes of `small_lane_cap` proofs for calls that fit them (several mid-size calls in flight at once); -1 = 2 for ChaCha20-V3, 0 for AES-V2
+    int small_lane_cap = 0;      // GSC_SMALL_LANE_CAP: their capacity (multiple of 64, at most GSC_MAX_BATCH); 0 = the engine's choice (1024 beside a larger full lane, else 512)
     size_t min_split = 0;        // > 0: a call with at least 2*min_split proofs that is alone on the replica is cut over the lanes (GSC_MIN_SPLIT: test hooks only; off by default, see prove_on_replica)
     int window_z = 0;            // digit width of the Z (quotient) rows: 2^(c-1) multiples of each of the n-1 bases; 0 = largest <= 16 that fits z_table_gb
     int window_w = 0;            // digit width of the A / B1 / B2 / K / commitment sets; 0 = largest <= 16 that fits w_table_gb

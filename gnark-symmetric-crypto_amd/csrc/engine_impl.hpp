@@ -158,7 +158,7 @@ class AlgorithmImpl {
     std::vector<std::unique_ptr<Lane>> lanes;
     size_t cap = 0;                     // proofs per full lane = the largest chunk
     size_t full_lanes = 0;              // lanes [0, full_lanes) hold `cap` proofs; the rest are small lanes (SMALL_LANE_CAP)
-    static constexpr size_t SMALL_LANE_CAP = 1024;     // 512 until round 4: two 1024-statement calls side by side prove 6 % more than one after the other on the full lane (profiles/r04m_lanes.txt)
+    static constexpr size_t SMALL_LANE_CAP = 1024;     // with full lanes larger than this; half of it otherwise (alloc in engine_tables.hip)
 
     AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const uint8_t* r1cs, size_t r1cs_len, const EngineConfig& cf);
     ~AlgorithmImpl() { lanes.clear(); if (stream) (void)hipStreamDestroy(stream); }

@@ -58,7 +58,10 @@ AlgorithmImpl::AlgorithmImpl(Cipher c, const uint8_t* pk, size_t pk_len, const u
     // flight at once — without paying a full lane's memory for each (46 GB at 8192 proofs): extra lanes of SMALL_LANE_CAP proofs
     // (~3 GB each for ChaCha20-V3), taken by calls that fit them.  GSC_SMALL_LANES: default 2 for ChaCha20-V3; AES-V2 has two full lanes already.
     if (cfg.small_lanes < 0) cfg.small_lanes = has_commitment ? 0 : 2;
-    const size_t small_cap = lane_cap > SMALL_LANE_CAP ? SMALL_LANE_CAP : lane_cap;
+    // Capacity: 1024 where the full lane is larger than that (two 1024-statement calls side by side prove 6 % more than one after the other on the
+    // full lane, profiles/r04m_lanes.txt), 512 otherwise — with GSC_MAX_BATCH <= 1024 the all-resident configuration (three algorithms, 268 GiB)
+    // has 4.7 GiB to spare, and 2 x 2.9 GB more would cost the third algorithm one bit of its Z digits (tools/r04_mem_probe.py).
+    const size_t small_want = cfg.small_lane_cap ? (size_t)cfg.small_lane_cap : lane_cap > SMALL_LANE_CAP ? SMALL_LANE_CAP : SMALL_LANE_CAP / 2, small_cap = lane_cap > small_want ? small_want : lane_cap;
     for (int i = 0; i < cfg.small_lanes; i++) { lanes.emplace_back(new Lane); alloc_lane(*lanes.back(), small_cap); }
     lane_busy.assign(lanes.size(), 0);
     cap = lane_cap;
