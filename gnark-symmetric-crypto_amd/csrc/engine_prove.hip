@@ -371,7 +371,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         HIP_CHECK(hipMemsetAsync(ln.d_C.p + domain_n * B, 0, B * sizeof(fe), ln.stream));
         run_msm_g1(ln, mC, ln.d_C.p, 1, B, ln.d_sumC.p);
     }
-    if (overlap_q) HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev[2], 0));           // d and its digits
+    if (overlap_q) { HIP_CHECK(hipEventRecord(ln.ev_ws, ln.stream)); HIP_CHECK(hipStreamWaitEvent(ln.stream, ln.ev[2], 0)); }      // the wire sets are through; wait for d and its digits
     run_msm_g1(ln, use_zfew ? mZfew : mZ, ln.d_A.p, 0, B, ln.d_sumZ.p, !latency_call, false, z_digits_ready);
     if (has_commitment) run_msm_g1(ln, mPedSigma, ln.d_W.p, 1, B, ln.d_sumPok.p);      // proof of knowledge of the commitment: same scalars over sigma * Basis
     flush_horner_g1(ln, B, ln.stream);                                           // K, Z, PedSigma: one launch
@@ -413,6 +413,14 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     }
     if (few_solver) few_penalty.store(16);
     for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, ln.ev[k], ln.ev[k + 1]); ln.stage_ms[k] = ms; }
+    if (overlap_q) {
+        // The quotient ran beside the wire-set MSMs: the stages stay a partition of the call's time, with the shared span charged to the MSMs —
+        // msm = (witness end .. wire sets through) + (quotient end .. MSMs through), quotient = what it still ran alone after the wire sets
+        float ws = 0, q = ln.stage_ms[1];
+        (void)hipEventElapsedTime(&ws, ln.ev[1], ln.ev_ws);
+        if (ws > q) ws = q;
+        ln.stage_ms[1] = q - ws; ln.stage_ms[2] += ws;
+    }
     (void)hipEventElapsedTime(&ln.msm_z_kernel_ms, ln.ev[5], ln.ev[6]); ln.last_batch = B;
     {
         KernelStat& st = ln.stat;

@@ -487,6 +487,7 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
         HIP_CHECK(hipStreamCreateWithPriority(&ln.side2, hipStreamDefault, least));
     } else { HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side)); HIP_CHECK(hipStreamCreate(&ln.side2)); }
     for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipEventCreate(&ln.ev_ws));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_few, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ln.ev_ab, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_fs, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_b2, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ln.ev_s2, hipEventDisableTiming));
     ln.h_in.alloc(176 * B); ln.h_rs.alloc(64 * B); ln.h_glv.alloc(2 * MSM_FEW_PROOFS); ln.h_out.alloc(256 * B); ln.h_flags.alloc((B + 3) / 4 * 4); ln.h_status.alloc(B); ln.h_words.alloc(56);
