@@ -623,7 +623,7 @@ def main():
             line["roofline"]["whole_path_frac"] = round(value / ngpu * bpp / 1e9 / HBM_PEAK_GBS, 6)
             line["msm_stage"] = line["roofline"].pop("msm_stage")
             line["stage_ms_last_step"] = line["roofline"].pop("stage_ms_last_step")
-            if "+beside-wire-sets" in str(line["config"].get("engine")):
+            if "+beside-wire-sets" in str(line["config"].get("engine")) and ("+beside-wire-sets(<4096)" not in str(line["config"].get("engine")) or B < 4096):
                 line["stage_note"] = ("the quotient kernels run on a stream of their own beside the wire-set MSMs (A, B1, B2, K, c); the span they share is charged to "
                                       "'msm', 'quotient' is what the quotient still ran alone afterwards; per-kernel times: profiles/r04_kernel_stats*.csv")
             if len(roofs) > 1:

@@ -52,7 +52,8 @@ EngineConfig config_from_env() {
     c.small_witness = env_int("GSC_SMALL_WITNESS", 1);
     c.small_witness_few = env_int("GSC_SMALL_WITNESS_FEW", 1);
     c.ntt_plain = env_int("GSC_NTT_PLAIN", 1) ? 1 : 0;
-    c.overlap_quotient = env_int("GSC_OVERLAP_QUOTIENT", 1) ? 1 : 0;
+    c.overlap_quotient = env_int("GSC_OVERLAP_QUOTIENT", 1);
+    if (c.overlap_quotient < 0 || c.overlap_quotient > 2) throw std::runtime_error("GSC_OVERLAP_QUOTIENT must be 0, 1 or 2");
     c.stream_priorities = env_int("GSC_STREAM_PRIORITIES", 1) ? 1 : 0;
     if (test_hooks_enabled()) { c.win_slice = env_int("GSC_WIN_SLICE", 256); if (c.win_slice < 64 || c.win_slice > 4096 || c.win_slice % 8) throw std::runtime_error("GSC_WIN_SLICE must be a multiple of 8 in [64, 4096]"); }
     if (c.small_witness < 0 || c.small_witness > 2 || (c.small_witness == 2 && !test_hooks_enabled())) throw std::runtime_error("GSC_SMALL_WITNESS must be 0 or 1");
@@ -128,7 +129,7 @@ std::string Algorithm::describe() const {
              impl_->mA.nwide, impl_->mA.nexpanded, impl_->mB1.nwide, impl_->mB1.nexpanded, impl_->mK.nwide, impl_->mK.nexpanded);
     // per replica: calls and statements it has served (ReplicaPicker): shows that small calls reach every device
     std::string out = buf;
-    if (impl_->quotient_eval) out += std::string(" quotient=evaluation-form") + (impl_->fuse_z_digits ? "+digits" : "") + (impl_->fuse_z_digits && impl_->cfg.overlap_quotient ? "+beside-wire-sets" : "") + "(c: " + std::to_string(impl_->mC.nbit) + " grouped + " + std::to_string(impl_->mC.nflat - impl_->mC.nbit) + " flat + " + std::to_string(impl_->mC.nwide) + " windowed)";
+    if (impl_->quotient_eval) out += std::string(" quotient=evaluation-form") + (impl_->fuse_z_digits ? "+digits" : "") + (!impl_->fuse_z_digits || !impl_->cfg.overlap_quotient ? "" : impl_->cfg.overlap_quotient == 2 ? "+beside-wire-sets" : "+beside-wire-sets(<4096)") + "(c: " + std::to_string(impl_->mC.nbit) + " grouped + " + std::to_string(impl_->mC.nflat - impl_->mC.nbit) + " flat + " + std::to_string(impl_->mC.nwide) + " windowed)";
     else out += " quotient=coefficient-form";
     out += impl_->small.ok ? " witness=small-integer(" + std::to_string(impl_->small.n_levels) + " chained levels, fallbacks " + std::to_string(impl_->small_fallbacks.load()) + ")" : " witness=generic" + (impl_->small.why.empty() ? std::string() : "(" + impl_->small.why + ")");
     out += " served(calls/statements)=";

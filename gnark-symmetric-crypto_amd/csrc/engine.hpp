@@ -57,7 +57,7 @@ struct EngineConfig {
                                  // (wit_small.hpp) in every call beyond the latency path; 0 = always the generic field-arithmetic solver;
                                  // 2 (test hooks only) = every constraint row predicted narrow: the kernels notice, the chunk is solved again generically
     int ntt_plain = 1;           // GSC_NTT_PLAIN: with byte planes, the first transform kernel works on the small integers themselves (its first two stages become integer scalings
-    int overlap_quotient = 1;    // GSC_OVERLAP_QUOTIENT: batch calls run the quotient kernels on the lane's third stream beside the wire-set MSMs (both only read the witness); 0 = one after the other
+    int overlap_quotient = 1;    // GSC_OVERLAP_QUOTIENT: batch calls run the quotient kernels on the lane's third stream beside the wire-set MSMs (both only read the witness) when they hold fewer than 4096 statements; 0 = one after the other; 2 = whatever the size
     int stream_priorities = 1;   // GSC_STREAM_PRIORITIES: a lane's three streams at three priority levels = in three pools of hardware queues (alloc_lane); 0 = plain streams
                                  // of twiddles); 0 = on their Montgomery images, like the generic path.  Same bytes either way
     int small_witness_few = 1;   // GSC_SMALL_WITNESS_FEW: calls on the latency path take it too (one workgroup walks the levels: no device-wide barriers); 0 = they keep the resident lanes-are-terms solver

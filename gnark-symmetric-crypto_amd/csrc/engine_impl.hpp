@@ -107,6 +107,7 @@ class AlgorithmImpl {
     DevBuf<uint32_t> ws_tiny, ws_parts, ws_bits, ws_twire, ws_levels, ws_rtiny, ws_rgen, ws_rtwire; DevBuf<long long> ws_tcoef, ws_rtcoef;
     DevBuf<uint8_t> ws_cls_a, ws_cls_b, ws_cls_c;      // per constraint row: 0 = byte plane, 1 = 32-byte element
     void init_small(const SolverProgram& sp);
+    static constexpr size_t OVERLAP_QUOTIENT_BELOW = 4096;      // batch calls smaller than this run the quotient beside the wire-set MSMs (prove_chunk)
     std::atomic<uint64_t> small_fallbacks{0};      // chunks that had to be solved again generically (gsc_describe)
     // NTT
     DevBuf<int32_t> tw_fwd, tw_inv, tw_inv_plain, qr; DevBuf<fe> scale_mid, scale_mid_plain, scale_out, dom;   // dom: omega, omega_inv, g, g_inv, n_inv, 16/n

@@ -329,8 +329,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
     // three quotient kernels go to the lane's third stream and the wire sets' thin tails (slice reductions, Horner chains, recoders: 5 ms of
     // a 1024-statement call's 54, none of it chip-filling) run under them; the Z sum waits for both.  Measured (profiles/r04k_overlap_quotient.txt):
     // 64 / 256 / 512 / 1024 statements per call +2 / +8 / +6 / +3.5 %, 8192 +0.1 %, AES-128 1024 / 256 per call +2.8 / +7 % — once the lanes'
-    // streams stopped sharing hardware queues (alloc_lane); before that, calls on the small lanes lost 2 - 5 % to it.
-    const bool overlap_q = z_digits_ready && !dbg && cfg.overlap_quotient != 0;
+    // streams stopped sharing hardware queues (alloc_lane); before that, calls on the small lanes lost 2 - 5 % to it.  Calls of 4096 statements
+    // and more keep the one-stream order: nothing to gain (their tails are 1 % of the call), and the stage times stay those of the kernels.
+    const bool overlap_q = z_digits_ready && !dbg && (cfg.overlap_quotient == 2 || (cfg.overlap_quotient && B < OVERLAP_QUOTIENT_BELOW));
     hipStream_t qs = overlap_q ? ln.side2 : ln.stream;
     if (eval) {
         if (dbg) {      // the debug vector is h itself: the coefficient-form kernels on copies (they overwrite their inputs)

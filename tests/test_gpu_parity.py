@@ -276,7 +276,7 @@ def test_engine_options_do_not_change_the_proofs():
                   {"GSC_FUSE_Z_DIGITS": "0"}, {"GSC_FUSE_Z_DIGITS": "0", "GSC_WINDOW_Z": "11"},
                   # GSC_OVERLAP_QUOTIENT=0: the quotient kernels before the wire-set MSMs on one stream instead of beside them on the lane's third;
                   # GSC_STREAM_PRIORITIES=0: the lane's streams all at the default priority (shared hardware queues)
-                  {"GSC_OVERLAP_QUOTIENT": "0"}, {"GSC_OVERLAP_QUOTIENT": "0", "GSC_LANES": "2"}, {"GSC_STREAM_PRIORITIES": "0"}, {"GSC_STREAM_PRIORITIES": "0", "GSC_LANES": "2"}):
+                  {"GSC_OVERLAP_QUOTIENT": "0"}, {"GSC_OVERLAP_QUOTIENT": "0", "GSC_LANES": "2"}, {"GSC_OVERLAP_QUOTIENT": "2"}, {"GSC_STREAM_PRIORITIES": "0"}, {"GSC_STREAM_PRIORITIES": "0", "GSC_LANES": "2"}):
         assert _digest(extra) == base, extra
 
 
