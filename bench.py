@@ -106,7 +106,7 @@ def roofline_valu_of(roof, rows, simds):
     valu_ms = nwin * VALU_ONLY_MS_PER_WINDOW_8192 * (cols / 8192.0) * (nb / 32768.0)
     return {"kernel": roof["kernel"], "bound": "valu-issue", "instr_per_wave_add": ipa, "instr_source": src,
             "wave_adds_per_launch": wave_adds, "windows": nwin, "simds": simds, "clock_mhz": round(mhz, 1),
-            "clock_source": "live: shader-clock / 100 MHz-clock stamps of eight waves spread over each timed launch, averaged",
+            "clock_source": "live: shader-clock / 100 MHz-clock stamps of eight waves spread over each timed launch, one on each XCD, averaged",
             "launch_ms": ms, "cycles_per_wave_instr": round(cpi, 4), "issue_floor_cycles": WAVE64_ISSUE_CYCLES, "frac": round(WAVE64_ISSUE_CYCLES / cpi, 4),
             "valu_only_ms": round(valu_ms, 2), "valu_only_source": "%.1f ms per window of 32 768 bases at 8192 columns with every gather forced onto one entry (profiles/r02_window_sweep.txt), scaled by columns and bases" % VALU_ONLY_MS_PER_WINDOW_8192,
             "miss_clock_loss_ms": round(ms - valu_ms, 2)}

@@ -428,7 +428,9 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         st.name = latency_call ? (small_call ? "k_wit_chain + k_wit_rows" : few_solver ? (has_commitment ? "k_solver_few + commitment MSM" : "k_solver_few") : "k_solver (one launch per level)") : "k_msm_win<Fp29f>";
         st.ms = ln.msm_z_kernel_ms; st.statements = n; st.columns = B; st.nbases = mZ.nwide; st.nwin = mZ.nwin;
         for (int k = 0; k < 4; k++) st.stage_ms[k] = ln.stage_ms[k];
-        // shader clock of the Z launch: (shader-clock ticks) / (100 MHz ticks) over the lives of eight waves spread over the grid
+        // shader clock of the Z launch: (shader-clock ticks) / (100 MHz ticks) over the lives of eight waves spread over the grid, one on each XCD
+        // (the XCDs are clocked separately; a pair of stamps from two different waves is useless: the shader-clock counters are not chip-wide —
+        // first-start-to-last-end read 1 772 ... 2 323 MHz on launches whose waves all saw 2 010 ... 2 069)
         double ticks = 0, shader = 0;
         if (!latency_call) for (int k = 0; k < 8; k++) { const unsigned long long* c = h_clk + 4 * k; if (c[2] > c[0] && c[3] > c[1]) { ticks += (double)(c[2] - c[0]); shader += (double)(c[3] - c[1]); } }
         st.clock_mhz = ticks > 0 ? (float)(100.0 * shader / ticks) : 0.f;
@@ -442,7 +444,7 @@ void AlgorithmImpl::prove_chunk(Lane& ln, const ProofRequest* reqs, size_t n, Pr
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "prove_chunk(%zu): enqueue %.2f ms, wait %.2f ms, serialise %.2f ms\n", n, ms(tc0, tc1), ms(tc1, tc2), ms(tc2, tc3));
         auto mhz = [&](int k) { const unsigned long long* c = h_clk + 4 * k; return c[2] > c[0] && c[3] > c[1] ? 100.0 * (double)(c[3] - c[1]) / (double)(c[2] - c[0]) : 0.0; };
-        if (!latency_call) fprintf(stderr, "prove_chunk(%zu): shader clock (one workgroup in the middle of each launch): transforms %.0f / %.0f / %.0f MHz, Z kernel %.0f MHz (eight waves); stages %.2f / %.2f / %.2f / %.2f ms\n", n, mhz(8), mhz(9), mhz(10), (double)ln.stat.clock_mhz,
+        if (!latency_call) fprintf(stderr, "prove_chunk(%zu): shader clock (one workgroup in the middle of each launch): transforms %.0f / %.0f / %.0f MHz, Z kernel %.0f MHz (eight waves, one per XCD: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f); stages %.2f / %.2f / %.2f / %.2f ms\n", n, mhz(8), mhz(9), mhz(10), (double)ln.stat.clock_mhz, mhz(0), mhz(1), mhz(2), mhz(3), mhz(4), mhz(5), mhz(6), mhz(7),
                                    ln.stage_ms[0], ln.stage_ms[1], ln.stage_ms[2], ln.stage_ms[3]);
     }
 }

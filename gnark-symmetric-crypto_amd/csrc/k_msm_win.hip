@@ -281,10 +281,11 @@ __global__ __launch_bounds__(64, F::WORDS == 1 ? 3 : 1) void k_msm_win(MsmWinArg
     // XCD-aware order: workgroups go round-robin over the 8 XCDs by linear id and each XCD has its own L2.  Every wave of a slice
     // (all windows, all groups of proofs) gathers from the same table rows, so a slice is placed on ONE XCD (consecutive ids there).
     const size_t G = a.batch / 64, GW = G * (size_t)a.nwin, L = blockIdx.x, S8 = a.nslices & ~(size_t)7;
-    // clock stamps: eight waves spread over the launch (at 1/16, 3/16, ... of the grid) each record {100 MHz clock, shader clock} at their start and end
-    const uint32_t eighth = gridDim.x / 8;
-    const bool stamp = a.clk && eighth && threadIdx.x == 0 && blockIdx.x % eighth == eighth / 2 && blockIdx.x / eighth < 8;
-    unsigned long long* const clk = a.clk + (stamp ? 4 * (blockIdx.x / eighth) : 0);
+    // clock stamps: eight waves spread over the launch (at 1/16, 3/16, ... of the grid), the k-th shifted by k workgroups so that each lands on another
+    // XCD (workgroups go round-robin over the XCDs, which are clocked separately), each record {100 MHz clock, shader clock} at their start and end
+    const uint32_t eighth = gridDim.x / 8, k8 = eighth ? blockIdx.x / eighth : 8u;
+    const bool stamp = a.clk && eighth >= 16 && threadIdx.x == 0 && k8 < 8 && blockIdx.x % eighth == eighth / 2 + k8;
+    unsigned long long* const clk = a.clk + (stamp ? 4 * k8 : 0);
     if (stamp) { clk[0] = wall_clock64(); clk[1] = clock64(); }
     size_t slice, rem;
     if (L < S8 * GW) { const size_t xcd = L & 7, i = L >> 3; slice = (i / GW) * 8 + xcd; rem = i % GW; }
