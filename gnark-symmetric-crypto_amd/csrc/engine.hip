@@ -54,7 +54,8 @@ EngineConfig config_from_env() {
     c.ntt_plain = env_int("GSC_NTT_PLAIN", 1) ? 1 : 0;
     c.overlap_quotient = env_int("GSC_OVERLAP_QUOTIENT", 1);
     if (c.overlap_quotient < 0 || c.overlap_quotient > 2) throw std::runtime_error("GSC_OVERLAP_QUOTIENT must be 0, 1 or 2");
-    c.stream_priorities = env_int("GSC_STREAM_PRIORITIES", 1) ? 1 : 0;
+    c.stream_priorities = env_int("GSC_STREAM_PRIORITIES", 1);      // 0 plain; 1 = main normal, side high, third low; 3-digit codes (test hook): one digit per stream, 1 high 2 normal 3 low
+    if (c.stream_priorities != 0 && c.stream_priorities != 1 && !(hooks && c.stream_priorities >= 111 && c.stream_priorities <= 333)) throw std::runtime_error("GSC_STREAM_PRIORITIES must be 0 or 1");
     if (test_hooks_enabled()) { c.win_slice = env_int("GSC_WIN_SLICE", 256); if (c.win_slice < 64 || c.win_slice > 4096 || c.win_slice % 8) throw std::runtime_error("GSC_WIN_SLICE must be a multiple of 8 in [64, 4096]"); }
     if (c.small_witness < 0 || c.small_witness > 2 || (c.small_witness == 2 && !test_hooks_enabled())) throw std::runtime_error("GSC_SMALL_WITNESS must be 0 or 1");
     if (c.few_workgroups < 0 || c.few_workgroups > 256) throw std::runtime_error("GSC_FEW_WGS must be in [0, 256]");

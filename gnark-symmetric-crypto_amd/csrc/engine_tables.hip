@@ -482,9 +482,11 @@ void AlgorithmImpl::alloc_lane(Lane& ln, size_t B) {
     int least = 0, greatest = 0;
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     if (cfg.stream_priorities && least != greatest) {
-        HIP_CHECK(hipStreamCreateWithPriority(&ln.stream, hipStreamDefault, (least + greatest) / 2));
-        HIP_CHECK(hipStreamCreateWithPriority(&ln.side, hipStreamDefault, greatest));
-        HIP_CHECK(hipStreamCreateWithPriority(&ln.side2, hipStreamDefault, least));
+        const int code = cfg.stream_priorities == 1 ? 213 : cfg.stream_priorities;      // digits: main, side, third; 1 high, 2 normal, 3 low
+        auto level = [&](int d) { return d == 1 ? greatest : d == 3 ? least : (least + greatest) / 2; };
+        HIP_CHECK(hipStreamCreateWithPriority(&ln.stream, hipStreamDefault, level(code / 100)));
+        HIP_CHECK(hipStreamCreateWithPriority(&ln.side, hipStreamDefault, level(code / 10 % 10)));
+        HIP_CHECK(hipStreamCreateWithPriority(&ln.side2, hipStreamDefault, level(code % 10)));
     } else { HIP_CHECK(hipStreamCreate(&ln.stream)); HIP_CHECK(hipStreamCreate(&ln.side)); HIP_CHECK(hipStreamCreate(&ln.side2)); }
     for (auto& e : ln.ev) HIP_CHECK(hipEventCreate(&e));
     HIP_CHECK(hipEventCreate(&ln.ev_ws));
